@@ -1,0 +1,123 @@
+"""The CPU oracle (oracle/slim_oracle.py) against golden vectors produced by the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import slim_oracle as O
+from conftest import synth_weight
+
+
+def test_g1_scaler_row_and_gram(golden):
+    g = golden("g1_stats")
+    X = g["X"]
+    sr, n = torch.zeros(64), 0
+    H, nh = torch.zeros(64, 64), 0
+    for j in range(4):
+        sr, n = O.add_batch_scaler_row(sr, n, X[j])
+        H, nh = O.add_batch_gram(H, nh, X[j])
+    assert n == int(g["nsamples"])
+    assert torch.equal(sr, g["scaler_row"])
+    assert torch.equal(H, g["H"])
+    # diag(H)/2 is the same statistic
+    torch.testing.assert_close(torch.diag(H) / 2, sr, rtol=1e-5, atol=0)
+    sr2, n2 = torch.zeros(64), 0
+    sr2, n2 = O.add_batch_scaler_row(sr2, n2, X[:2, 0])
+    sr2, n2 = O.add_batch_scaler_row(sr2, n2, X[2:, 0])
+    assert n2 == int(g["nsamples_b2"]) and torch.equal(sr2, g["scaler_row_b2"])
+
+
+def test_g2_shift_zeros(golden):
+    g = golden("g2_shift_zeros")
+    for a, b in (("v", "out"), ("v2", "out2"), ("v3", "out3")):
+        assert torch.equal(O.shift_zeros(g[a]), g[b])
+
+
+def test_g3_prune_nm(golden):
+    g = golden("g3_prune_nm")
+    for n in (1, 2, 3):
+        assert torch.equal(O.prune_nm(g["tuples"], n, 4), g[f"mask_n{n}"].bool())
+    assert torch.equal(O.prune_nm(g["rand"], 2, 4), g["rand_mask_2_4"].bool())
+    sal = O.saliency(g["W"], g["scaler_row"])
+    assert torch.equal(sal, g["saliency"])
+    for n in (1, 2, 3):
+        assert torch.equal(O.prune_nm(sal, n, 4), g[f"sal_mask_{n}_4"].bool())
+    assert torch.equal(O.prune_nm(g["special"], 2, 4), g["special_mask_2_4"].bool())
+
+
+def _case_weight(g, tag):
+    if tag + "_seed_shape" in g:
+        seed, n, k = [int(v) for v in g[tag + "_seed_shape"]]
+        if tag == "uniform_edge":
+            return (torch.rand(n, k, generator=torch.Generator().manual_seed(seed)) * 2 - 1).to(torch.bfloat16)
+        return synth_weight(n, k, seed)
+    return g[tag + "_W"]
+
+
+@pytest.mark.parametrize("tag", ["bins512", "bins589", "bins2359", "heavy", "masked", "bins20000", "uniform_edge"])
+def test_g4_scale_search(golden, tag):
+    g = golden("g4_g5_slim_quant")
+    W = _case_weight(g, tag)
+    alpha, idx, pdf, val, trace = O.find_optimal_quantization_cap(W, 4, O.num_bins_for(W.numel()), return_trace=True)
+    assert torch.equal(pdf, g[tag + "_pdf"]) and torch.equal(val, g[tag + "_val"])
+    assert [t[0] for t in trace] == g[tag + "_eval_idx"].tolist()
+    assert np.array_equal(np.array([t[1] for t in trace], dtype=np.float32), g[tag + "_eval_loss"].numpy())
+    # the fixture's "alpha" is 7 / scaling_factor (a round trip), so the pin is the scaling factor itself
+    assert abs(float(alpha) - float(g[tag + "_alpha"])) <= 1e-6 * float(alpha)
+    codes, sf = O.quantize_per_tensor(W, 4, abs_max=alpha)
+    assert torch.equal(sf, g[tag + "_sf"])
+    if tag + "_codes" in g:
+        assert torch.equal(codes, g[tag + "_codes"])
+        assert torch.equal(O.dequantize_per_tensor(codes, sf).to(torch.bfloat16), g[tag + "_deq_bf16cast"])
+    else:
+        assert int(codes.long().sum()) == int(g[tag + "_codes_sum"])
+        assert torch.equal(torch.bincount((codes.long() + 8).flatten(), minlength=16), g[tag + "_codes_hist"])
+
+
+def test_g5_variants_and_ties(golden):
+    g = golden("g4_g5_slim_quant")
+    W = g["bins512_W"]
+    c, sf = O.quantize_per_tensor(W, 4, slim_quant=False)
+    assert torch.equal(c, g["bins512_b4_sq0_codes"]) and torch.equal(sf, g["bins512_b4_sq0_sf"])
+    c, sf = O.quantize_per_tensor(W, 8, slim_quant=True)
+    assert torch.equal(c, g["bins512_b8_sq1_codes"]) and torch.equal(sf, g["bins512_b8_sq1_sf"])
+    c, sf = O.quantize_per_tensor(W, 8, slim_quant=False)
+    assert torch.equal(c, g["bins512_b8_sq0_codes"]) and torch.equal(sf, g["bins512_b8_sq0_sf"])
+    c, _ = O.quantize_per_tensor(g["ties_W"], 4, abs_max=torch.tensor(7.0))
+    assert torch.equal(c, g["ties_codes_sf1"])
+
+
+def test_g6_group_quant(golden):
+    g = golden("g6_group_quant")
+    for tag in ("a", "b", "c"):
+        x, blk = g[tag + "_x"], int(g[tag + "_blk"])
+        for q in (4, 8):
+            al = O.group_quant_params(x, blk)
+            assert torch.equal(al, g[f"{tag}_q{q}_alphas"])
+            codes = O.group_quantize(x, al, q)
+            assert torch.equal(codes, g[f"{tag}_q{q}_codes"])
+            deq = O.group_dequantize(codes, al, q)
+            ref = g[f"{tag}_q{q}_deq"]
+            # the golden comes from the Triton CPU interpreter, which truncates fp32 -> bf16:
+            # allow one bf16 ulp, and require exactness wherever the fp32 value is representable
+            d = (deq.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+            assert int(d.max()) <= 1
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "naive"])
+def test_g7_add_lora(golden, tag):
+    g = golden("g7_add_lora")
+    W, sr, mask, tile = g[tag + "_W"], g[tag + "_scaler_row"], g[tag + "_mask"].bool(), int(g[tag + "_tile"])
+    out = O.add_lora(W, mask, sr, 0.1, num_bits=4, tile=tile)
+    assert torch.equal(out["weight"], g[tag + "_new_weight"])
+    assert torch.equal(out["lora_left"], g[tag + "_lora_left"])
+    assert torch.equal(out["lora_right"], g[tag + "_lora_right"])
+    assert torch.equal(out["scaling_factor"], g[tag + "_sf2"])
+
+
+def test_g9_input_quant(golden):
+    g = golden("g9_input_quant")
+    for tag in ("small", "large"):
+        x = g[tag + "_x"]
+        assert torch.equal(O.quantize_input_fp8(x.clone()), g[f"{tag}_b8_g-1"])
+        assert torch.equal(O.quantize_input_int(x.clone(), 4, 64), g[f"{tag}_b4_g64"])
+        assert torch.equal(O.quantize_input_int(x.clone(), 6, -1), g[f"{tag}_b6_g-1"])
