@@ -1,0 +1,158 @@
+/*
+ * slim_hip.h - C ABI of libslim_hip.so: the SLiM per-layer compression hot path as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless a comment says "host".  Buffers are
+ *     caller-allocated, row-major, and never freed or retained by the library.
+ *   - bf16 tensors are passed as `void*` (raw 16-bit patterns); weights are [N, K]
+ *     (out_features x in_features), the layout of nn.Linear.weight.
+ *   - `stream` is a hipStream_t (NULL = the default stream).  All work is enqueued on it;
+ *     nothing synchronises the host.
+ *   - Return value: 0 on success, negative on error (SLIM_ERR_*); slim_last_error() gives
+ *     the message for the calling thread.  Nothing throws.
+ *   - Reference citations are file:line in the sempfi/slim checkout this library replaces.
+ */
+#ifndef SLIM_HIP_H
+#define SLIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLIM_HIP_ABI_VERSION 1
+#define SLIM_FIT_INFO_WORDS 64
+
+int slim_abi_version(void);
+const char* slim_last_error(void); /* host string, valid until the next failing call on this thread */
+
+/* ---- (1) calibration statistics -------------------------------------------------------- */
+
+/* WrappedGPT.add_batch, slim/layerwrapper.py:25-41, for `n_chunks` consecutive add_batch calls
+ * in one launch.  x is [n_chunks * rows_per_chunk, K] bf16 with row stride ld; chunk c is the
+ * input of one call carrying `batch_per_chunk` samples.  Applies, in order, per chunk:
+ *   scaler_row *= n / (n + b);  n += b;  scaler_row += ||x_chunk[:, col]||_2^2 / n
+ * scaler_row: fp32 [K], updated in place.  nsamples_before: n before the first chunk (host int).
+ * workspace: slim_colsumsq_workspace_bytes(...) bytes. */
+int64_t slim_colsumsq_workspace_bytes(int64_t n_chunks, int64_t rows_per_chunk, int64_t K);
+int slim_scaler_row_accum(const void* x, int64_t n_chunks, int64_t rows_per_chunk, int64_t K, int64_t ld,
+                          int64_t batch_per_chunk, float* scaler_row, int64_t nsamples_before, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
+/* SparseGPT.add_batch, slim/sparsegpt.py:28-39: H = H * n/(n+b) + (2/(n+b)) * X^T X, fp32 [K, K],
+ * X = [T, K] bf16 (T = b * tokens).  MFMA bf16 products, fp32 accumulation. */
+int64_t slim_gram_workspace_bytes(int64_t T, int64_t K);
+int slim_gram_accum(const void* x, int64_t T, int64_t K, int64_t ld, float* H, int64_t nsamples_before,
+                    int64_t batch, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* shift_zeros, slim/utils.py:64-72: out = in + min(in with zeros replaced by 1).  May alias. */
+int slim_shift_zeros(const float* in, float* out, int64_t K, void* stream);
+/* element-wise sqrt (torch.sqrt(scaler_row), slim/prune.py:264-265, slim/lora.py:146) */
+int slim_sqrt_f32(const float* in, float* out, int64_t K, void* stream);
+/* flag[0] = 1 if any element is zero (the `any(scaler_row == 0)` guard of slim/lora.py:139) */
+int slim_any_zero_f32(const float* in, int64_t K, int32_t* flag, void* stream);
+
+/* ---- (2) N:M mask ------------------------------------------------------------------------ */
+
+/* Saliency + prune_nm fused: metric = |W| * s[col] (slim/prune.py:264-265, s = sqrt(scaler_row);
+ * s = NULL: metric = |W|), then in every aligned group of m columns the n smallest metrics are
+ * marked 1 = pruned (slim/utils.py:75-88), with the reference's tie behaviour.  mask: uint8 [N, K].
+ * Implemented for m = 4, n in 1..3; other patterns return SLIM_ERR_UNSUPPORTED. */
+int slim_mask_nm(const void* W_bf16, const float* s, int64_t N, int64_t K, int n, int m, uint8_t* mask,
+                 void* stream);
+/* prune_nm on an arbitrary fp32 metric matrix, slim/utils.py:75-88. */
+int slim_prune_nm_f32(const float* metric, int64_t N, int64_t K, int n, int m, uint8_t* mask, void* stream);
+/* HOST: the 729-entry tie table of the 4-wide selection (index = base-3 digits of the six pairwise
+ * comparisons 01,02,03,12,13,23 with 0: <, 1: ==, 2: >; value = bit i set if element i is selected). */
+int slim_nm_lut4(int n, uint8_t* out729_host);
+
+/* ---- (3) SLiM-Quant scale search and per-tensor quantisation ------------------------------- */
+
+/* Exact histogram of |w| over the 32768 non-negative bf16 bit patterns; hist: uint32 [32768].
+ * accumulate = 0 zeroes hist first.  Replaces the torch.histogram pass of quantization.py:36. */
+int slim_hist_abs_bf16(const void* W_bf16, int64_t numel, uint32_t* hist, int accumulate, void* stream);
+
+/* find_optimal_quantiztion_cap, slim/quantization/quantization.py:34-62 with compute_average_error
+ * :6-20, from the pattern histogram: rebuilds the reference's density histogram over
+ * [min|w|, max|w|] with num_bins bins, runs the coarse (every num_bins/10) and fine scans and
+ * returns alpha = val[argmin] (device float), its bin index, and sf = (2^(bits-1)-1) / alpha.
+ * idx_out, sf_out may be NULL. */
+int64_t slim_quant_search_workspace_bytes(int num_bins);
+int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out, int32_t* idx_out,
+                      float* sf_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* abs-max scale (slim_quant = False, quantization.py:190-194): alpha = max|w| (bf16 value),
+ * sf = bf16(maxq / alpha) widened to fp32. */
+int slim_absmax_scale(const uint32_t* hist, int num_bits, float* alpha_out, float* sf_out, void* stream);
+
+/* Quantizer.quantize_block, quantization.py:194-200:
+ *   codes = clamp(round_half_even(float(bf16(float(w) * sf))), -2^(b-1), 2^(b-1)-1) as int8. */
+int slim_quantize_pt(const void* W_bf16, int64_t numel, const float* sf, int num_bits, int8_t* codes, void* stream);
+/* Quantizer.dequantize_absmax (1,1) branch, quantization.py:211-212: float(code) / sf, as fp32
+ * (out_bf16 = 0) or rounded to bf16 (out_bf16 = 1). */
+int slim_dequantize_pt(const int8_t* codes, int64_t numel, const float* sf, void* out, int out_bf16, void* stream);
+/* quantise + dequantise + bf16 cast in one pass (the weight written back at slim/lora.py:203-209);
+ * codes may be NULL. */
+int slim_fake_quant_pt(const void* W_bf16, int64_t numel, const float* sf, int num_bits, void* out_bf16,
+                       int8_t* codes, void* stream);
+
+/* ---- (4) low-rank fit of the compression error ----------------------------------------------- */
+
+/* Error matrix of add_lora, slim/lora.py:146-156 (s != NULL) or :158-169 (s = NULL):
+ *   E = float(W) * s - mask0((code / sf) * s);   sf = NULL means "no quantiser" (:141-144).
+ * Written as fp32 and/or bf16 (either pointer may be NULL). */
+int slim_error_matrix(const void* W_bf16, const uint8_t* mask, const float* s, const float* sf, int num_bits,
+                      int64_t N, int64_t K, float* E_f32, void* E_bf16, void* stream);
+
+int slim_transpose_bf16(const void* in, int64_t R, int64_t C, void* out, void* stream);
+
+/* C[M, N] = alpha * A[M, Kd] * Bt[N, Kd]^T + beta * C_f32, bf16 operands (reduction dimension
+ * contiguous), fp32 accumulation on MFMA.  Any of C_f32 [M, N], C_bf16 [M, N], Ct_bf16 [N, M] may be
+ * NULL; beta != 0 requires C_f32. */
+int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd, float alpha,
+                      float beta, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16, void* Ct_bf16,
+                      int64_t ldct, void* stream);
+
+/* Replaces torch.svd + truncation, slim/lora.py:172-185 (+ the bf16 division by sqrt(scaler_row)
+ * of :193-195 when s != NULL).  Randomized subspace iteration: l = r + oversampling columns,
+ * n_iter power iterations.
+ *   E [N, K], Et [K, N] bf16;  outputs U [N, r], Ut [r, N] (= lora_right, may be NULL),
+ *   L [K, r] (= lora_left), S fp32 [r] (may be NULL), info_out int32 [SLIM_FIT_INFO_WORDS]
+ *   (rocSOLVER status words, all zero on success; may be NULL). */
+int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l);
+int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter, uint32_t seed,
+                     const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
+/* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
+ * N x K low-rank product itself) is written too when non-NULL. */
+int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W_bf16,
+                          const uint8_t* mask, void* Wn_bf16, void* LR_bf16, void* stream);
+/* Same subtraction from a materialised LR, optionally accumulating the |bf16| histogram of Wn. */
+int slim_residual_weight(const void* W_bf16, const void* LR_bf16, const uint8_t* mask, int64_t numel, void* Wn_bf16,
+                         uint32_t* hist, void* stream);
+
+int slim_randn_bf16(void* out, int64_t n, uint32_t seed, void* stream);
+int slim_scale_rows_bf16(void* L, const float* s, int64_t K, int64_t r, void* stream);
+
+/* ---- (5) group quantisation of the adapters ---------------------------------------------------- */
+
+/* compute_quantization_params(x, block, 1, symmetric=True), slim/quantization/utils.py:254-271:
+ * alphas bf16 [M / block, N] = max |x| over each block of rows, per column. */
+int slim_group_absmax(const void* x_bf16, int64_t M, int64_t N, int block, void* alphas_bf16, void* stream);
+/* quantize_tensor, utils.py:123-128 (+ :12-31): int8 codes, round half toward zero. */
+int slim_group_quantize(const void* x_bf16, const void* alphas_bf16, int64_t M, int64_t N, int block, int bits,
+                        int8_t* codes, void* stream);
+/* dequantize_tensor, utils.py:188-193 (+ :34-47): bf16 output. */
+int slim_group_dequantize(const int8_t* codes, const void* alphas_bf16, int64_t M, int64_t N, int block, int bits,
+                          void* out_bf16, void* stream);
+/* The three above in one pass (quantize_lora, slim/lora.py:91-97; QuantizedMatmul.forward,
+ * quantization.py:313-317); alphas_bf16 and codes may be NULL. */
+int slim_group_fake_quant(const void* x_bf16, int64_t M, int64_t N, int block, int bits, void* out_bf16,
+                          void* alphas_bf16, int8_t* codes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIM_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libslim_hip.so (declared in include/slim_hip.h).
+
+The library is the only compute path of this package: if it is missing the import fails
+loudly; there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslim_hip.so")
+
+vp, i64, i32, f32, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/slim_hip.h one to one
+PROTOTYPES = {
+    "slim_abi_version": (i32, []),
+    "slim_last_error": (C.c_char_p, []),
+    "slim_colsumsq_workspace_bytes": (i64, [i64, i64, i64]),
+    "slim_scaler_row_accum": (i32, [vp, i64, i64, i64, i64, i64, vp, i64, vp, i64, vp]),
+    "slim_gram_workspace_bytes": (i64, [i64, i64]),
+    "slim_gram_accum": (i32, [vp, i64, i64, i64, vp, i64, i64, vp, i64, vp]),
+    "slim_shift_zeros": (i32, [vp, vp, i64, vp]),
+    "slim_sqrt_f32": (i32, [vp, vp, i64, vp]),
+    "slim_any_zero_f32": (i32, [vp, i64, vp, vp]),
+    "slim_mask_nm": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
+    "slim_prune_nm_f32": (i32, [vp, i64, i64, i32, i32, vp, vp]),
+    "slim_nm_lut4": (i32, [i32, vp]),
+    "slim_hist_abs_bf16": (i32, [vp, i64, vp, i32, vp]),
+    "slim_quant_search_workspace_bytes": (i64, [i32]),
+    "slim_quant_search": (i32, [vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "slim_absmax_scale": (i32, [vp, i32, vp, vp, vp]),
+    "slim_quantize_pt": (i32, [vp, i64, vp, i32, vp, vp]),
+    "slim_dequantize_pt": (i32, [vp, i64, vp, vp, i32, vp]),
+    "slim_fake_quant_pt": (i32, [vp, i64, vp, i32, vp, vp, vp]),
+    "slim_error_matrix": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
+    "slim_transpose_bf16": (i32, [vp, i64, i64, vp, vp]),
+    "slim_gemm_nt_bf16": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, f32, vp, i64, vp, i64, vp, i64, vp]),
+    "slim_lowrank_fit_workspace_bytes": (i64, [i64, i64, i64]),
+    "slim_lowrank_fit": (i32, [vp, vp, i64, i64, i32, i32, i32, u32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "slim_lowrank_residual": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "slim_residual_weight": (i32, [vp, vp, vp, i64, vp, vp, vp]),
+    "slim_randn_bf16": (i32, [vp, i64, u32, vp]),
+    "slim_scale_rows_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "slim_group_absmax": (i32, [vp, i64, i64, i32, vp, vp]),
+    "slim_group_quantize": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
+    "slim_group_dequantize": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
+    "slim_group_fake_quant": (i32, [vp, i64, i64, i32, i32, vp, vp, vp, vp]),
+}
+
+ERR_INVALID, ERR_LAUNCH, ERR_UNSUPPORTED, ERR_SOLVER = -1, -2, -3, -4
+
+
+class SlimHipError(RuntimeError):
+    def __init__(self, name, code, msg):
+        super().__init__(f"{name} failed ({code}): {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m slim_amd.build` (needs hipcc). "
+            "slim_amd has no fallback path without its HIP library.")
+    # torch must be imported first so that the process-wide HIP runtime is the one torch uses
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.slim_last_error().decode(errors="replace")
+        if rc == ERR_UNSUPPORTED:
+            raise NotImplementedError(f"{name}: {msg}")
+        if rc == ERR_INVALID:
+            raise ValueError(f"{name}: {msg}")
+        raise SlimHipError(name, rc, msg)
+
+
+def query(name, *args):
+    """Call an entry point that returns a value (workspace sizes, version)."""
+    return getattr(load(), name)(*args)

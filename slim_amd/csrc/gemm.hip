@@ -1,0 +1,317 @@
+// bf16 MFMA GEMM, "NT" form:  C[M,N] = alpha * A[M,Kd] * Bt[N,Kd]^T, fp32 accumulation.
+// Both operands are row-major with the reduction dimension contiguous, which is the layout
+// every product of the low-rank fit is arranged to have (the tall matrices are kept both
+// as X and X^T; this kernel can emit C, bf16(C) and bf16(C)^T in one pass for that purpose).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave as 4x4
+// v_mfma_f32_16x16x32_bf16 fragments), K-step 64, register-staged global->LDS copies with
+// the next tile's loads issued before the current tile's MFMAs, two LDS buffers, one barrier
+// per K-step.  LDS rows are padded by 8 elements (144-byte stride) so the 16 rows read by a
+// ds_read_b128 lane group fall on distinct banks.
+#include "common.hpp"
+#include "../../include/slim_hip.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define LDS_STRIDE (BK + 8)
+
+struct GemmArgs {
+    const bf16_t* A;
+    int64_t lda;
+    const bf16_t* B;
+    int64_t ldb;
+    int M, N, Kd;
+    float alpha, beta;  // C32 = alpha * acc + beta * C32 (beta = 0: C32 is not read)
+    float* C32;
+    int64_t ldc32;
+    bf16_t* C16;
+    int64_t ldc16;
+    bf16_t* Ct16;
+    int64_t ldct;
+    // optional fused epilogue of the adapter subtraction (slim/lora.py:199-201):
+    // Wn = mask ? 0 : bf16(float(W) - float(bf16(acc)))
+    const bf16_t* W;
+    const uint8_t* mask;
+    bf16_t* Wn;
+    int64_t ldw;
+};
+
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
+                                          u16x8 (&r)[4]) {
+    const int t = threadIdx.x;
+    const int kc = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = row0 + (t >> 3) + 32 * i;
+        row = row < rows ? row : rows - 1;
+        const int k = k0 + kc;
+        if (k < Kd) r[i] = *(const u16x8*)(P + (int64_t)row * ld + k);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[i][j] = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[4]) {
+    const int t = threadIdx.x;
+    const int kc = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 3) + 32 * i;
+        *(u16x8*)(lds + row * LDS_STRIDE + kc) = r[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    // buffer b: A tile at smem + b * 2 * BM * LDS_STRIDE, B tile right after it
+    auto As = [&](int b) { return smem + b * 2 * BM * LDS_STRIDE; };
+    auto Bs = [&](int b) { return smem + b * 2 * BM * LDS_STRIDE + BM * LDS_STRIDE; };
+
+    // XCD-aware tile order: consecutive hardware workgroup ids round-robin over the 8 XCDs, so give
+    // each XCD a contiguous run of tiles (neighbouring tiles share an A or B panel in that XCD's L2).
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u16x8 ra[4], rb[4];
+    const int nk = (g.Kd + BK - 1) / BK;
+    load_tile(g.A, g.lda, g.M, g.Kd, row0, 0, ra);
+    load_tile(g.B, g.ldb, g.N, g.Kd, col0, 0, rb);
+    store_tile(As(0), ra);
+    store_tile(Bs(0), rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile(g.A, g.lda, g.M, g.Kd, row0, (kt + 1) * BK, ra);
+            load_tile(g.B, g.ldb, g.N, g.Kd, col0, (kt + 1) * BK, rb);
+        }
+        const bf16_t* a_base = As(cur) + (wr * 64 + fr) * LDS_STRIDE + fq * 8;
+        const bf16_t* b_base = Bs(cur) + (wc * 64 + fr) * LDS_STRIDE + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(a_base + i * 16 * LDS_STRIDE + ks * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_base + j * 16 * LDS_STRIDE + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_tile(As(cur ^ 1), ra);
+            store_tile(Bs(cur ^ 1), rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: fragment (i, j): rows row0 + wr*64 + i*16 + fq*4 + reg, column col0 + wc*64 + j*16 + fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col0 + wc * 64 + j * 16 + fr;
+            const int rbase = row0 + wr * 64 + i * 16 + fq * 4;
+            if (col >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] * g.alpha;
+                if (g.beta != 0.f && rbase + r < g.M) v[r] += g.beta * g.C32[(int64_t)(rbase + r) * g.ldc32 + col];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + r;
+                if (row >= g.M) continue;
+                if (g.C32) g.C32[(int64_t)row * g.ldc32 + col] = v[r];
+                if (g.C16) g.C16[(int64_t)row * g.ldc16 + col] = f32_to_bf16(v[r]);
+                if (g.Wn) {
+                    const int64_t o = (int64_t)row * g.ldw + col;
+                    const float lr = round_bf16(v[r]);
+                    g.Wn[o] = g.mask[o] ? (bf16_t)0 : f32_to_bf16(bf16_to_f32(g.W[o]) - lr);
+                }
+            }
+            if (g.Ct16) {
+                bf16_t* p = g.Ct16 + (int64_t)col * g.ldct + rbase;
+                if (rbase + 3 < g.M && (g.ldct & 3) == 0) {
+                    u16x4 o = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                    *(u16x4*)p = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rbase + r < g.M) p[r] = f32_to_bf16(v[r]);
+                }
+            }
+        }
+    }
+}
+
+static int gemm_launch(const GemmArgs& g, void* stream) {
+    SLIM_REQUIRE(g.A && g.B && g.M > 0 && g.N > 0 && g.Kd > 0, "slim_gemm_nt_bf16: bad arguments");
+    SLIM_REQUIRE(g.Kd % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.lda >= g.Kd && g.ldb >= g.Kd,
+                 "slim_gemm_nt_bf16: Kd, lda, ldb must be multiples of 8 and ld >= Kd");
+    SLIM_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "slim_gemm_nt_bf16: operands must be 16-byte aligned");
+    SLIM_REQUIRE(g.C32 || g.C16 || g.Ct16 || g.Wn, "slim_gemm_nt_bf16: no output requested");
+    SLIM_REQUIRE(!g.Ct16 || ((uintptr_t)g.Ct16 % 8) == 0, "slim_gemm_nt_bf16: Ct must be 8-byte aligned");
+    const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
+    const int lds_bytes = 4 * BM * LDS_STRIDE * (int)sizeof(bf16_t);
+    SLIM_HIP(slim_allow_dynamic_lds((const void*)gemm_nt_kernel, lds_bytes));
+    gemm_nt_kernel<<<(unsigned)tiles, 256, lds_bytes, (hipStream_t)stream>>>(g);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+extern "C" int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
+                                 float alpha, float beta, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16,
+                                 void* Ct_bf16, int64_t ldct, void* stream) {
+    SLIM_REQUIRE(beta == 0.f || C_f32, "slim_gemm_nt_bf16: beta needs C_f32");
+    GemmArgs g{};
+    g.beta = beta;
+    g.A = (const bf16_t*)A;
+    g.lda = lda;
+    g.B = (const bf16_t*)Bt;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.Kd = Kd;
+    g.alpha = alpha;
+    g.C32 = C_f32;
+    g.ldc32 = ldc32;
+    g.C16 = (bf16_t*)C_bf16;
+    g.ldc16 = ldc16;
+    g.Ct16 = (bf16_t*)Ct_bf16;
+    g.ldct = ldct;
+    return gemm_launch(g, stream);
+}
+
+// Wn[N,K] = mask ? 0 : bf16(W - bf16(U[N,r] * L[K,r]^T)) : the adapter product of slim/lora.py:199
+// fused with the subtraction and masking of :200-201, so the N x K low-rank matrix is never stored.
+extern "C" int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W,
+                                     const uint8_t* mask, void* Wn, void* LR_bf16, void* stream) {
+    SLIM_REQUIRE(W && mask && Wn, "slim_lowrank_residual: null pointer");
+    GemmArgs g{};
+    g.A = (const bf16_t*)U;
+    g.lda = r;
+    g.B = (const bf16_t*)L;
+    g.ldb = r;
+    g.M = N;
+    g.N = K;
+    g.Kd = r;
+    g.alpha = 1.f;
+    g.C16 = (bf16_t*)LR_bf16;
+    g.ldc16 = K;
+    g.W = (const bf16_t*)W;
+    g.mask = mask;
+    g.Wn = (bf16_t*)Wn;
+    g.ldw = K;
+    return gemm_launch(g, stream);
+}
+
+// ---- bf16 transpose through a padded LDS tile ----------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t R, int64_t C,
+                                                             bf16_t* __restrict__ out) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[r * C + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[c * R + r] = tile[tx][i];
+    }
+}
+
+extern "C" int slim_transpose_bf16(const void* in, int64_t R, int64_t C, void* out, void* stream) {
+    SLIM_REQUIRE(in && out && R > 0 && C > 0, "slim_transpose_bf16: bad arguments");
+    SLIM_REQUIRE(ceil_div64(R, 64) <= 65535, "slim_transpose_bf16: too many rows");
+    dim3 grid((unsigned)ceil_div64(C, 64), (unsigned)ceil_div64(R, 64));
+    transpose_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)in, R, C, (bf16_t*)out);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// ---- Gram statistic (reference slim/sparsegpt.py:28-39) -------------------------------------------
+// H = H * n/(n+b) + (2/(n+b)) X^T X.  X [T, K] is transposed chunk-wise into the workspace so the
+// product runs in the NT form with the token dimension contiguous.
+#define GRAM_CHUNK 4096
+extern "C" int64_t slim_gram_workspace_bytes(int64_t T, int64_t K) {
+    if (T <= 0 || K <= 0) return 0;
+    const int64_t c = T < GRAM_CHUNK ? ((T + 7) / 8) * 8 : GRAM_CHUNK;
+    return K * c * 2;
+}
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ in, int64_t R, int64_t C,
+                                                            int64_t ld, bf16_t* __restrict__ out, int64_t Rpad) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[r * ld + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rpad) out[c * Rpad + r] = tile[tx][i];
+    }
+}
+
+extern "C" int slim_gram_accum(const void* x, int64_t T, int64_t K, int64_t ld, float* H, int64_t nsamples_before,
+                               int64_t batch, void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(x && H && workspace && T > 0 && K > 0 && batch > 0 && nsamples_before >= 0, "slim_gram_accum: bad arguments");
+    SLIM_REQUIRE(K % 8 == 0 && ld >= K, "slim_gram_accum: K must be a multiple of 8");
+    SLIM_REQUIRE(workspace_bytes >= slim_gram_workspace_bytes(T, K), "slim_gram_accum: workspace too small");
+    const double n1 = (double)(nsamples_before + batch);
+    const float alpha = (float)(2.0 / n1);
+    const float beta = (float)((double)nsamples_before / n1);
+    const bf16_t* xb = (const bf16_t*)x;
+    bf16_t* xt = (bf16_t*)workspace;
+    bool first = true;
+    for (int64_t t0 = 0; t0 < T; t0 += GRAM_CHUNK) {
+        const int64_t rows = T - t0 < GRAM_CHUNK ? T - t0 : GRAM_CHUNK;
+        const int64_t rpad = ((rows + 7) / 8) * 8;
+        dim3 grid((unsigned)ceil_div64(K, 64), (unsigned)ceil_div64(rpad, 64));
+        transpose_pad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(xb + t0 * ld, rows, K, ld, xt, rpad);
+        SLIM_LAUNCH_CHECK();
+        GemmArgs g{};
+        g.A = xt;
+        g.lda = rpad;
+        g.B = xt;
+        g.ldb = rpad;
+        g.M = (int)K;
+        g.N = (int)K;
+        g.Kd = (int)rpad;
+        g.alpha = alpha;
+        g.beta = first ? beta : 1.f;
+        g.C32 = H;
+        g.ldc32 = K;
+        int rc = gemm_launch(g, stream);
+        if (rc) return rc;
+        first = false;
+    }
+    return SLIM_OK;
+}

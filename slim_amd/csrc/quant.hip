@@ -1,0 +1,564 @@
+// SLiM-Quant: |W| histogram, clipping-threshold search, per-tensor symmetric quantisation
+// (reference slim/quantization/quantization.py:6-20, 34-62, 133-217) and the element-wise
+// stages of add_lora that surround the low-rank fit (slim/lora.py:146-156, 199-204).
+//
+// Histogram design.  The weights are bf16, so |W| takes at most 32768 distinct values.  One
+// pass over W counts every bit pattern exactly in a 128 KiB LDS table per workgroup (one
+// workgroup per CU); no min/max pre-pass is needed and the result does not depend on a bin
+// range.  The reference's `torch.histogram(|W|, bins, density=True)` over [min|W|, max|W|]
+// is then re-derived from the 32768 exact counts by a single small workgroup, using the same
+// fp32 edge formula (step = (hi-lo)/bins; edge_i = fma(step, i, lo) in the lower half,
+// fma(-step, bins-i, hi) in the upper half), the same "largest edge <= v" binning with the
+// last bin closed, and the same density normalisation (count/total)/width.
+#include "common.hpp"
+#include "../../include/slim_hip.h"
+
+#define HIST_BINS 32768
+#define MAX_SEARCH_BINS 20000
+
+// ---- exact |bf16| histogram ------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hist_bf16_kernel(const bf16_t* __restrict__ w, int64_t numel,
+                                                         uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
+    for (int i = threadIdx.x; i < HIST_BINS; i += 1024) lh[i] = 0;
+    __syncthreads();
+    const int64_t nvec = numel >> 3;
+    uint32_t zeros = 0;
+    for (int64_t v = (int64_t)blockIdx.x * 1024 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 1024) {
+        const u16x8 x = *(const u16x8*)(w + (v << 3));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t b = x[j] & 0x7fffu;
+            // zeros (half of a masked matrix) would serialise on one LDS word: count them in a register
+            zeros += (b == 0);
+            if (b != 0) atomicAdd(&lh[b], 1u);
+        }
+    }
+    // tail elements (numel not a multiple of 8): handled by block 0
+    if (blockIdx.x == 0) {
+        const int64_t t = (nvec << 3) + threadIdx.x;
+        if (t < numel) atomicAdd(&lh[w[t] & 0x7fffu], 1u);
+    }
+    zeros = wave_sum_u32(zeros);
+    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&lh[0], zeros);
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_BINS; i += 1024) {
+        const uint32_t c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+extern "C" int slim_hist_abs_bf16(const void* W, int64_t numel, uint32_t* hist, int accumulate, void* stream) {
+    SLIM_REQUIRE(W && hist && numel > 0, "slim_hist_abs_bf16: bad arguments");
+    SLIM_REQUIRE(((uintptr_t)W % 16) == 0, "slim_hist_abs_bf16: W must be 16-byte aligned");
+    SLIM_REQUIRE(numel < ((int64_t)1 << 32), "slim_hist_abs_bf16: more than 2^32 elements");
+    hipStream_t st = (hipStream_t)stream;
+    SLIM_HIP(slim_allow_dynamic_lds((const void*)hist_bf16_kernel, HIST_BINS * 4));
+    if (!accumulate) SLIM_HIP(hipMemsetAsync(hist, 0, HIST_BINS * sizeof(uint32_t), st));
+    int64_t blocks = ceil_div64(numel >> 3, 1024 * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256) blocks = 256;
+    hist_bf16_kernel<<<(unsigned)blocks, 1024, HIST_BINS * 4, st>>>((const bf16_t*)W, numel, hist);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// ---- search workspace layout (floats) ---------------------------------------------------
+//  [0, B)            pdf
+//  [B, 2B)           val (bin centres)
+//  [2B, 3B)          total_loss (inf where not evaluated)
+//  [3B, 3B+16)       coarse losses (11 used)
+//  [3B+16, 3B+32)    coarse indices as int32 (11 used), then scalars
+struct SearchWs {
+    float* pdf;
+    float* val;
+    float* total_loss;
+    float* coarse_loss;
+    int32_t* coarse_idx;
+};
+__host__ __device__ static inline SearchWs search_ws(float* base, int B) {
+    SearchWs w;
+    w.pdf = base;
+    w.val = base + B;
+    w.total_loss = base + 2 * (int64_t)B;
+    w.coarse_loss = base + 3 * (int64_t)B;
+    w.coarse_idx = (int32_t*)(base + 3 * (int64_t)B + 16);
+    return w;
+}
+
+extern "C" int64_t slim_quant_search_workspace_bytes(int num_bins) {
+    if (num_bins <= 0) return 0;
+    return ((int64_t)3 * num_bins + 32) * (int64_t)sizeof(float);
+}
+
+__device__ __forceinline__ float edge_at(int i, int bins, float lo, float hi, float step) {
+    const int half = (bins + 1) / 2;
+    return i < half ? __fmaf_rn(step, (float)i, lo) : __fmaf_rn(-step, (float)(bins - i), hi);
+}
+
+// Single workgroup: rebuild the reference's density histogram from the exact pattern counts.
+__global__ __launch_bounds__(1024) void rebin_kernel(const uint32_t* __restrict__ hist, int bins, float* ws_base) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // bins counts
+    __shared__ int s_lo, s_hi;
+    __shared__ unsigned long long s_total;
+    SearchWs ws = search_ws(ws_base, bins);
+    if (threadIdx.x == 0) {
+        s_lo = HIST_BINS;
+        s_hi = -1;
+        s_total = 0ull;
+    }
+    for (int i = threadIdx.x; i < bins; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    int lo_p = HIST_BINS, hi_p = -1;
+    unsigned long long tot = 0;
+    for (int p = threadIdx.x; p < HIST_BINS; p += 1024) {
+        const uint32_t c = hist[p];
+        if (c) {
+            lo_p = min(lo_p, p);
+            hi_p = max(hi_p, p);
+            tot += c;
+        }
+    }
+    atomicMin(&s_lo, lo_p);
+    atomicMax(&s_hi, hi_p);
+    atomicAdd(&s_total, tot);
+    __syncthreads();
+    float lo = bf16_to_f32((bf16_t)s_lo), hi = bf16_to_f32((bf16_t)s_hi);
+    if (s_lo == s_hi) {  // constant |W|: the reference widens the range by half a unit each side
+        lo -= 0.5f;
+        hi += 0.5f;
+    }
+    const float step = (hi - lo) / (float)bins;
+    for (int p = threadIdx.x; p < HIST_BINS; p += 1024) {
+        const uint32_t c = hist[p];
+        if (!c) continue;
+        const float v = bf16_to_f32((bf16_t)p);
+        int pos = (int)((v - lo) / (hi - lo) * (float)bins);
+        pos = max(0, min(pos, bins - 1));
+        while (pos > 0 && v < edge_at(pos, bins, lo, hi, step)) --pos;
+        while (pos + 1 < bins && v >= edge_at(pos + 1, bins, lo, hi, step)) ++pos;
+        atomicAdd(&cnt[pos], c);
+    }
+    __syncthreads();
+    const float total = (float)s_total;
+    for (int i = threadIdx.x; i < bins; i += 1024) {
+        const float e0 = edge_at(i, bins, lo, hi, step), e1 = edge_at(i + 1, bins, lo, hi, step);
+        const float width = e1 - e0;
+        ws.pdf[i] = ((float)cnt[i] / total) / width;
+        ws.val[i] = (e0 + e1) / 2.0f;
+        ws.total_loss[i] = __builtin_inff();
+    }
+    if (threadIdx.x < 16) {
+        ws.coarse_loss[threadIdx.x] = __builtin_inff();
+        ws.coarse_idx[threadIdx.x] = 0;
+    }
+}
+
+// floor division of non-negative fp32 values as the reference's `//` computes it
+// (fmod-based, with the half-way correction), b > 0.
+__device__ __forceinline__ float floor_div_f32(float a, float b) {
+    const float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.f && mod < 0.f) div -= 1.f;
+    if (div == 0.f) return 0.f;
+    float fl = floorf(div);
+    if (div - fl > 0.5f) fl += 1.f;
+    return fl;
+}
+
+// loss of one candidate index, reduced over the workgroup (256 threads); element-wise terms
+// are formed with the reference's fp32 operations, the sum is carried in fp64.
+__device__ float candidate_loss(const SearchWs& ws, int bins, int index, int q, double* red) {
+    const float alpha = ws.val[index];
+    const float dx = ws.val[1] - ws.val[0];
+    const float step = alpha / (float)(1 << q);
+    double sq = 0.0, sc = 0.0;
+    for (int j = threadIdx.x; j < bins; j += 256) {
+        const float v = ws.val[j], p = ws.pdf[j];
+        if (j < index) {
+            const float qv = (step == 0.f ? (v / step) : floor_div_f32(v, step)) * step;
+            const float d = v - qv;
+            sq += (double)(p * (d * d));
+        } else {
+            const float d = v - alpha;
+            sc += (double)(p * (d * d));
+        }
+    }
+    sq = wave_sum_d(sq);
+    sc = wave_sum_d(sc);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wv] = sq;
+        red[4 + wv] = sc;
+    }
+    __syncthreads();
+    const double tq = red[0] + red[1] + red[2] + red[3];
+    const double tc = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+    return (float)tq * dx + (float)tc * dx;
+}
+
+// phase 0: coarse scan, block b evaluates index b * (bins / 10)
+// phase 1: fine scan of [indices[max(tp-1,0)], indices[min(tp+1,10)]), block b evaluates start + b
+__global__ __launch_bounds__(256) void search_loss_kernel(float* ws_base, int bins, int q, int phase) {
+    __shared__ double red[8];
+    SearchWs ws = search_ws(ws_base, bins);
+    if (phase == 0) {
+        const int i = blockIdx.x * (bins / 10);
+        if (i >= bins) return;
+        const float l = candidate_loss(ws, bins, i, q, red);
+        if (threadIdx.x == 0) {
+            ws.coarse_loss[blockIdx.x] = l;
+            ws.coarse_idx[blockIdx.x] = i;
+        }
+    } else {
+        int tp = 0;
+        float best = ws.coarse_loss[0];
+        for (int j = 1; j < 11; ++j) {
+            const float l = ws.coarse_loss[j];
+            if (l < best) {  // first minimum wins, as torch.min does
+                best = l;
+                tp = j;
+            }
+        }
+        const int start = ws.coarse_idx[max(tp - 1, 0)];
+        const int end = ws.coarse_idx[min(tp + 1, 10)];
+        const int i = start + (int)blockIdx.x;
+        if (i >= end) return;
+        const float l = candidate_loss(ws, bins, i, q, red);
+        if (threadIdx.x == 0) ws.total_loss[i] = l;
+    }
+}
+
+// argmin (first occurrence) of total_loss; outputs alpha = val[idx], idx, scaling factor maxq / alpha.
+__global__ __launch_bounds__(1024) void search_argmin_kernel(const float* ws_base, int bins, int num_bits,
+                                                             float* alpha_out, int32_t* idx_out, float* sf_out) {
+    __shared__ float bl[16];
+    __shared__ int bi[16];
+    SearchWs ws = search_ws((float*)ws_base, bins);
+    float best = __builtin_inff();
+    int besti = 0x7fffffff;
+    for (int i = threadIdx.x; i < bins; i += 1024) {
+        const float l = ws.total_loss[i];
+        if (l < best) {
+            best = l;
+            besti = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ol = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ol < best || (ol == best && oi < besti)) {
+            best = ol;
+            besti = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        bl[threadIdx.x >> 6] = best;
+        bi[threadIdx.x >> 6] = besti;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bl[w] < best || (bl[w] == best && bi[w] < besti)) {
+                best = bl[w];
+                besti = bi[w];
+            }
+        if (besti == 0x7fffffff) besti = 0;  // every loss inf: index 0, like torch.min on an all-inf vector
+        const float alpha = ws.val[besti];
+        alpha_out[0] = alpha;
+        if (idx_out) idx_out[0] = besti;
+        if (sf_out) sf_out[0] = (float)((1 << (num_bits - 1)) - 1) / alpha;
+    }
+}
+
+extern "C" int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out,
+                                 int32_t* idx_out, float* sf_out, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    SLIM_REQUIRE(hist && alpha_out && workspace, "slim_quant_search: null pointer");
+    SLIM_REQUIRE(num_bins >= 10 && num_bins <= MAX_SEARCH_BINS, "slim_quant_search: num_bins must be in [10, 20000]");
+    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 16, "slim_quant_search: num_bits out of range");
+    SLIM_REQUIRE(workspace_bytes >= slim_quant_search_workspace_bytes(num_bins), "slim_quant_search: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    SLIM_HIP(slim_allow_dynamic_lds((const void*)rebin_kernel, MAX_SEARCH_BINS * 4));
+    float* ws = (float*)workspace;
+    rebin_kernel<<<1, 1024, (size_t)num_bins * 4, st>>>(hist, num_bins, ws);
+    SLIM_LAUNCH_CHECK();
+    const int stride = num_bins / 10;
+    const int ncoarse = (num_bins + stride - 1) / stride;  // 10 or 11 points
+    search_loss_kernel<<<ncoarse, 256, 0, st>>>(ws, num_bins, num_bits, 0);
+    SLIM_LAUNCH_CHECK();
+    search_loss_kernel<<<2 * stride, 256, 0, st>>>(ws, num_bins, num_bits, 1);
+    SLIM_LAUNCH_CHECK();
+    search_argmin_kernel<<<1, 1024, 0, st>>>(ws, num_bins, num_bits, alpha_out, idx_out, sf_out);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// abs-max of a bf16 tensor from its pattern histogram (the non-SLiM-Quant scale, quantization.py:190):
+// scaling factor = bf16(maxq / bf16 absmax), returned as fp32.
+__global__ __launch_bounds__(1024) void absmax_from_hist_kernel(const uint32_t* __restrict__ hist, int num_bits,
+                                                                float* alpha_out, float* sf_out) {
+    __shared__ int s_hi;
+    if (threadIdx.x == 0) s_hi = 0;
+    __syncthreads();
+    int hi_p = 0;
+    for (int p = threadIdx.x; p < HIST_BINS; p += 1024)
+        if (hist[p]) hi_p = max(hi_p, p);
+    atomicMax(&s_hi, hi_p);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = bf16_to_f32((bf16_t)s_hi);
+        alpha_out[0] = a;
+        if (sf_out) sf_out[0] = round_bf16((float)((1 << (num_bits - 1)) - 1) / a);
+    }
+}
+
+extern "C" int slim_absmax_scale(const uint32_t* hist, int num_bits, float* alpha_out, float* sf_out, void* stream) {
+    SLIM_REQUIRE(hist && alpha_out, "slim_absmax_scale: null pointer");
+    absmax_from_hist_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(hist, num_bits, alpha_out, sf_out);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// ---- per-tensor quantise / dequantise ---------------------------------------------------
+// code = clamp(round_half_even(float(bf16(float(w) * sf))), -2^(b-1), 2^(b-1)-1)
+__device__ __forceinline__ float quant_code(bf16_t w, float sf, float qmin, float qmax) {
+    const float prod = round_bf16(bf16_to_f32(w) * sf);
+    return fminf(fmaxf(rintf(prod), qmin), qmax);
+}
+
+__global__ __launch_bounds__(256) void quantize_pt_kernel(const bf16_t* __restrict__ w, int64_t numel,
+                                                          const float* __restrict__ sf_p, int num_bits,
+                                                          int8_t* __restrict__ codes) {
+    const float sf = sf_p[0];
+    const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
+    const int64_t nvec = numel >> 3;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const u16x8 x = *(const u16x8*)(w + (v << 3));
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo |= ((uint32_t)(uint8_t)(int8_t)(int)quant_code(x[j], sf, qmin, qmax)) << (8 * j);
+            hi |= ((uint32_t)(uint8_t)(int8_t)(int)quant_code(x[4 + j], sf, qmin, qmax)) << (8 * j);
+        }
+        *(uint2*)(codes + (v << 3)) = uint2{lo, hi};
+    }
+    if (blockIdx.x == 0) {
+        const int64_t t = (nvec << 3) + threadIdx.x;
+        if (t < numel) codes[t] = (int8_t)(int)quant_code(w[t], sf, qmin, qmax);
+    }
+}
+
+extern "C" int slim_quantize_pt(const void* W, int64_t numel, const float* sf, int num_bits, int8_t* codes,
+                                void* stream) {
+    SLIM_REQUIRE(W && sf && codes && numel > 0, "slim_quantize_pt: bad arguments");
+    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 8, "slim_quantize_pt: num_bits must be in [2, 8]");
+    SLIM_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)codes % 8) == 0, "slim_quantize_pt: misaligned pointer");
+    int64_t blocks = ceil_div64(numel >> 3, 256);
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    quantize_pt_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, numel, sf, num_bits, codes);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// out = float(code) / sf, stored as fp32 (out_bf16 = 0) or rounded to bf16 (out_bf16 = 1)
+__global__ __launch_bounds__(256) void dequantize_pt_kernel(const int8_t* __restrict__ codes, int64_t numel,
+                                                            const float* __restrict__ sf_p, void* __restrict__ out,
+                                                            int out_bf16) {
+    const float sf = sf_p[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float v = (float)codes[i] / sf;
+        if (out_bf16) ((bf16_t*)out)[i] = f32_to_bf16(v);
+        else ((float*)out)[i] = v;
+    }
+}
+
+extern "C" int slim_dequantize_pt(const int8_t* codes, int64_t numel, const float* sf, void* out, int out_bf16,
+                                  void* stream) {
+    SLIM_REQUIRE(codes && sf && out && numel > 0, "slim_dequantize_pt: bad arguments");
+    int64_t blocks = ceil_div64(numel, 256);
+    blocks = blocks > 8192 ? 8192 : blocks;
+    dequantize_pt_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(codes, numel, sf, out, out_bf16);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// Fused quantise -> dequantise -> bf16 (the final `weight.data` of add_lora, lora.py:203-209),
+// optionally also emitting the int8 codes.
+__global__ __launch_bounds__(256) void fake_quant_pt_kernel(const bf16_t* __restrict__ w, int64_t numel,
+                                                            const float* __restrict__ sf_p, int num_bits,
+                                                            bf16_t* __restrict__ out, int8_t* __restrict__ codes) {
+    const float sf = sf_p[0];
+    const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
+    const int64_t nvec = numel >> 3;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const u16x8 x = *(const u16x8*)(w + (v << 3));
+        u16x8 o;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float c = quant_code(x[j], sf, qmin, qmax);
+            o[j] = f32_to_bf16(c / sf);
+            const uint32_t b = ((uint32_t)(uint8_t)(int8_t)(int)c) << (8 * (j & 3));
+            if (j < 4) lo |= b;
+            else hi |= b;
+        }
+        *(u16x8*)(out + (v << 3)) = o;
+        if (codes) *(uint2*)(codes + (v << 3)) = uint2{lo, hi};
+    }
+    if (blockIdx.x == 0) {
+        const int64_t t = (nvec << 3) + threadIdx.x;
+        if (t < numel) {
+            const float c = quant_code(w[t], sf, qmin, qmax);
+            out[t] = f32_to_bf16(c / sf);
+            if (codes) codes[t] = (int8_t)(int)c;
+        }
+    }
+}
+
+extern "C" int slim_fake_quant_pt(const void* W, int64_t numel, const float* sf, int num_bits, void* out_bf16,
+                                  int8_t* codes, void* stream) {
+    SLIM_REQUIRE(W && sf && out_bf16 && numel > 0, "slim_fake_quant_pt: bad arguments");
+    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 8, "slim_fake_quant_pt: num_bits must be in [2, 8]");
+    SLIM_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)out_bf16 % 16) == 0 && (!codes || ((uintptr_t)codes % 8) == 0),
+                 "slim_fake_quant_pt: misaligned pointer");
+    int64_t blocks = ceil_div64(numel >> 3, 256);
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    fake_quant_pt_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, numel, sf, num_bits,
+                                                                           (bf16_t*)out_bf16, codes);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// ---- error matrix of add_lora (lora.py:146-156) ------------------------------------------
+// E = float(W) * s - mask0((code / sf) * s), s = sqrt(scaler_row) per column (s == NULL: ones,
+// the "naive" branch lora.py:158-169).  sf == NULL: no quantisation (E = masked part of W * s).
+// Written as fp32 and/or bf16.
+__global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restrict__ w, const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ s, const float* __restrict__ sf_p,
+                                                           int num_bits, int64_t N, int64_t K,
+                                                           float* __restrict__ e32, bf16_t* __restrict__ e16) {
+    const float sf = sf_p ? sf_p[0] : 0.f;
+    const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
+    const int64_t cpr = K >> 3, total = N * cpr;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t row = t / cpr, c0 = (t - row * cpr) << 3, off = row * K + c0;
+        const u16x8 x = *(const u16x8*)(w + off);
+        const uint2 mk = *(const uint2*)(mask + off);
+        float sv[8];
+        if (s) {
+            const f32x4 a = *(const f32x4*)(s + c0), b = *(const f32x4*)(s + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sv[j] = a[j];
+                sv[4 + j] = b[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = 1.f;
+        }
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float wf = bf16_to_f32(x[j]);
+            const float metric = wf * sv[j];
+            const bool pruned = ((j < 4 ? mk.x >> (8 * j) : mk.y >> (8 * (j - 4))) & 0xffu) != 0;
+            float nw;
+            if (pruned) nw = 0.f;
+            else if (sf_p) nw = (quant_code(x[j], sf, qmin, qmax) / sf) * sv[j];
+            else nw = metric;
+            e[j] = metric - nw;
+        }
+        if (e32) {
+            *(f32x4*)(e32 + off) = f32x4{e[0], e[1], e[2], e[3]};
+            *(f32x4*)(e32 + off + 4) = f32x4{e[4], e[5], e[6], e[7]};
+        }
+        if (e16) {
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f32_to_bf16(e[j]);
+            *(u16x8*)(e16 + off) = o;
+        }
+    }
+}
+
+extern "C" int slim_error_matrix(const void* W, const uint8_t* mask, const float* s, const float* sf, int num_bits,
+                                 int64_t N, int64_t K, float* E_f32, void* E_bf16, void* stream) {
+    SLIM_REQUIRE(W && mask && (E_f32 || E_bf16) && N > 0 && K > 0, "slim_error_matrix: bad arguments");
+    SLIM_REQUIRE(K % 8 == 0, "slim_error_matrix: K must be a multiple of 8");
+    SLIM_REQUIRE(!sf || (num_bits >= 2 && num_bits <= 8), "slim_error_matrix: num_bits must be in [2, 8]");
+    int64_t blocks = ceil_div64(N * (K >> 3), 256);
+    blocks = blocks > 8192 ? 8192 : blocks;
+    error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K,
+                                                                          E_f32, (bf16_t*)E_bf16);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// ---- residual weight (lora.py:199-201): Wn = bf16(float(W) - float(LR)), pruned entries 0 -----
+// Optionally accumulates the |bf16| pattern histogram of Wn for the second scale search through
+// a per-workgroup LDS table, saving one full read of Wn.
+template <bool WITH_HIST>
+__global__ __launch_bounds__(1024) void residual_weight_kernel(const bf16_t* __restrict__ w,
+                                                               const bf16_t* __restrict__ lr,
+                                                               const uint8_t* __restrict__ mask, int64_t numel,
+                                                               bf16_t* __restrict__ out, uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
+    if (WITH_HIST) {
+        for (int i = threadIdx.x; i < HIST_BINS; i += 1024) lh[i] = 0;
+        __syncthreads();
+    }
+    uint32_t zeros = 0;
+    const int64_t nvec = numel >> 3;
+    for (int64_t v = (int64_t)blockIdx.x * 1024 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 1024) {
+        const int64_t off = v << 3;
+        const u16x8 x = *(const u16x8*)(w + off);
+        const u16x8 l = *(const u16x8*)(lr + off);
+        const uint2 mk = *(const uint2*)(mask + off);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool pruned = ((j < 4 ? mk.x >> (8 * j) : mk.y >> (8 * (j - 4))) & 0xffu) != 0;
+            o[j] = pruned ? (bf16_t)0 : f32_to_bf16(bf16_to_f32(x[j]) - bf16_to_f32(l[j]));
+            if (WITH_HIST) {
+                const uint32_t b = o[j] & 0x7fffu;
+                zeros += (b == 0);
+                if (b != 0) atomicAdd(&lh[b], 1u);
+            }
+        }
+        *(u16x8*)(out + off) = o;
+    }
+    if (WITH_HIST) {
+        zeros = wave_sum_u32(zeros);
+        if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&lh[0], zeros);
+        __syncthreads();
+        for (int i = threadIdx.x; i < HIST_BINS; i += 1024) {
+            const uint32_t c = lh[i];
+            if (c) atomicAdd(&hist[i], c);
+        }
+    }
+}
+
+extern "C" int slim_residual_weight(const void* W, const void* LR, const uint8_t* mask, int64_t numel, void* out,
+                                    uint32_t* hist, void* stream) {
+    SLIM_REQUIRE(W && LR && mask && out && numel > 0, "slim_residual_weight: bad arguments");
+    SLIM_REQUIRE(numel % 8 == 0, "slim_residual_weight: numel must be a multiple of 8");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = ceil_div64(numel >> 3, 1024 * 2);
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    if (hist) {
+        SLIM_HIP(slim_allow_dynamic_lds((const void*)residual_weight_kernel<true>, HIST_BINS * 4));
+        SLIM_HIP(hipMemsetAsync(hist, 0, HIST_BINS * sizeof(uint32_t), st));
+        residual_weight_kernel<true><<<(unsigned)blocks, 1024, HIST_BINS * 4, st>>>(
+            (const bf16_t*)W, (const bf16_t*)LR, mask, numel, (bf16_t*)out, hist);
+    } else {
+        blocks = ceil_div64(numel >> 3, 1024);
+        blocks = blocks > 2048 ? 2048 : blocks;
+        residual_weight_kernel<false><<<(unsigned)blocks, 1024, 0, st>>>((const bf16_t*)W, (const bf16_t*)LR, mask, numel,
+                                                                        (bf16_t*)out, nullptr);
+    }
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}

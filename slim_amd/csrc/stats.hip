@@ -1,0 +1,161 @@
+// Calibration statistics: per-column sum of squares of the activations and the running
+// scaler_row recurrence of WrappedGPT.add_batch (reference slim/layerwrapper.py:25-41),
+// shift_zeros (slim/utils.py:64-72) and the element-wise square root used for the saliency.
+#include "common.hpp"
+#include "../../include/slim_hip.h"
+
+#define SLAB_ROWS 256
+
+// grid (col_blocks, slabs, chunks); each thread owns 8 consecutive columns and walks the
+// rows of its slab, so a wave reads 1 KiB contiguous per row.
+__global__ __launch_bounds__(256) void colsumsq_kernel(const bf16_t* __restrict__ x, int64_t rows_per_chunk,
+                                                       int64_t K, int64_t ld, float* __restrict__ partial,
+                                                       int slabs) {
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c0 >= K) return;
+    const int slab = blockIdx.y;
+    const int64_t chunk = blockIdx.z;
+    const int64_t r0 = (int64_t)slab * SLAB_ROWS;
+    int64_t r1 = r0 + SLAB_ROWS;
+    if (r1 > rows_per_chunk) r1 = rows_per_chunk;
+    const bf16_t* p = x + (chunk * rows_per_chunk + r0) * ld + c0;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        u16x8 v0 = *(const u16x8*)(p);
+        u16x8 v1 = *(const u16x8*)(p + ld);
+        u16x8 v2 = *(const u16x8*)(p + 2 * ld);
+        u16x8 v3 = *(const u16x8*)(p + 3 * ld);
+        p += 4 * ld;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = bf16_to_f32(v0[j]), b = bf16_to_f32(v1[j]), c = bf16_to_f32(v2[j]), d = bf16_to_f32(v3[j]);
+            acc[j] += a * a;
+            acc[j] += b * b;
+            acc[j] += c * c;
+            acc[j] += d * d;
+        }
+    }
+    for (; r < r1; ++r) {
+        u16x8 v0 = *(const u16x8*)(p);
+        p += ld;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = bf16_to_f32(v0[j]);
+            acc[j] += a * a;
+        }
+    }
+    float* o = partial + (chunk * slabs + slab) * K + c0;
+    *(f32x4*)(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+// One thread per column: fold the slab partials of every chunk in order and apply
+//   scaler_row *= n / (n + b); n += b; scaler_row += sqrt(sumsq)^2 / n
+// once per chunk (b = batch_per_chunk samples per add_batch call).
+__global__ void scaler_update_kernel(float* __restrict__ scaler_row, int64_t K, const float* __restrict__ partial,
+                                     int64_t n_chunks, int slabs, int64_t batch_per_chunk, int64_t n_before) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    float sr = scaler_row[c];
+    int64_t n = n_before;
+    for (int64_t ch = 0; ch < n_chunks; ++ch) {
+        float ss = 0.f;
+        for (int s = 0; s < slabs; ++s) ss += partial[(ch * slabs + s) * K + c];
+        const float f = (float)((double)n / (double)(n + batch_per_chunk));
+        sr = sr * f;
+        n += batch_per_chunk;
+        const float nrm = sqrtf(ss);
+        sr = sr + (nrm * nrm) / (float)n;
+    }
+    scaler_row[c] = sr;
+}
+
+extern "C" int64_t slim_colsumsq_workspace_bytes(int64_t n_chunks, int64_t rows_per_chunk, int64_t K) {
+    if (n_chunks <= 0 || rows_per_chunk <= 0 || K <= 0) return 0;
+    return n_chunks * ceil_div64(rows_per_chunk, SLAB_ROWS) * K * (int64_t)sizeof(float);
+}
+
+extern "C" int slim_scaler_row_accum(const void* x, int64_t n_chunks, int64_t rows_per_chunk, int64_t K, int64_t ld,
+                                     int64_t batch_per_chunk, float* scaler_row, int64_t nsamples_before,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(x && scaler_row && workspace, "slim_scaler_row_accum: null pointer");
+    SLIM_REQUIRE(n_chunks > 0 && rows_per_chunk > 0 && K > 0 && batch_per_chunk > 0 && nsamples_before >= 0,
+                 "slim_scaler_row_accum: bad sizes");
+    SLIM_REQUIRE(K % 8 == 0 && ld % 8 == 0 && ld >= K && ((uintptr_t)x % 16) == 0,
+                 "slim_scaler_row_accum: K and ld must be multiples of 8 and x 16-byte aligned");
+    SLIM_REQUIRE(workspace_bytes >= slim_colsumsq_workspace_bytes(n_chunks, rows_per_chunk, K),
+                 "slim_scaler_row_accum: workspace too small");
+    const int slabs = (int)ceil_div64(rows_per_chunk, SLAB_ROWS);
+    SLIM_REQUIRE(n_chunks <= 65535 && slabs <= 65535, "slim_scaler_row_accum: too many chunks/slabs for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)ceil_div64(K, 256 * 8), (unsigned)slabs, (unsigned)n_chunks);
+    colsumsq_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows_per_chunk, K, ld, (float*)workspace, slabs);
+    SLIM_LAUNCH_CHECK();
+    scaler_update_kernel<<<(unsigned)ceil_div64(K, 256), 256, 0, st>>>(scaler_row, K, (const float*)workspace, n_chunks,
+                                                                      slabs, batch_per_chunk, nsamples_before);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// ---- shift_zeros + sqrt ---------------------------------------------------------------
+// Single workgroup: m = min over (x == 0 ? 1 : x); out = x + m.  NaN propagates like torch.min.
+__global__ __launch_bounds__(1024) void shift_zeros_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int64_t K) {
+    __shared__ float red[16];
+    __shared__ int has_nan[1];
+    if (threadIdx.x == 0) has_nan[0] = 0;
+    __syncthreads();
+    float m = __builtin_inff();
+    bool nan = false;
+    for (int64_t i = threadIdx.x; i < K; i += 1024) {
+        float v = in[i];
+        if (v != v) nan = true;
+        if (v == 0.f) v = 1.f;
+        m = fminf(m, v);
+    }
+    if (nan) has_nan[0] = 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float mm = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mm = fminf(mm, red[w]);
+    if (has_nan[0]) mm = __builtin_nanf("");
+    for (int64_t i = threadIdx.x; i < K; i += 1024) out[i] = in[i] + mm;
+}
+
+__global__ void sqrt_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) out[i] = sqrtf(in[i]);
+}
+
+__global__ void any_zero_kernel(const float* __restrict__ in, int64_t K, int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K && in[i] == 0.f) atomicOr(flag, 1);
+}
+
+extern "C" int slim_shift_zeros(const float* in, float* out, int64_t K, void* stream) {
+    SLIM_REQUIRE(in && out && K > 0, "slim_shift_zeros: bad arguments");
+    shift_zeros_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(in, out, K);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+extern "C" int slim_sqrt_f32(const float* in, float* out, int64_t K, void* stream) {
+    SLIM_REQUIRE(in && out && K > 0, "slim_sqrt_f32: bad arguments");
+    sqrt_kernel<<<(unsigned)ceil_div64(K, 256), 256, 0, (hipStream_t)stream>>>(in, out, K);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+extern "C" int slim_any_zero_f32(const float* in, int64_t K, int32_t* flag, void* stream) {
+    SLIM_REQUIRE(in && flag && K > 0, "slim_any_zero_f32: bad arguments");
+    SLIM_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), (hipStream_t)stream));
+    any_zero_kernel<<<(unsigned)ceil_div64(K, 256), 256, 0, (hipStream_t)stream>>>(in, K, flag);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}

@@ -1,0 +1,278 @@
+"""Tensor-level wrappers over the C ABI (include/slim_hip.h).
+
+PyTorch is used for device memory and streams only: every function allocates its outputs
+with torch, passes raw device pointers and the current HIP stream to libslim_hip.so, and
+returns torch tensors.  Inputs must live on a ROCm device; nothing here computes on the CPU.
+"""
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be on the GPU: slim_amd has no CPU path (got device {t.device})")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---- calibration statistics -------------------------------------------------------------
+def scaler_row_accum(x, scaler_row, nsamples_before, n_chunks, batch_per_chunk):
+    """x: bf16 [n_chunks * rows, K]; scaler_row fp32 [K] updated in place (n_chunks add_batch calls)."""
+    x = _chk(x, BF16, "x")
+    _chk(scaler_row, torch.float32, "scaler_row")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    rows = x2.shape[0] // n_chunks
+    assert rows * n_chunks == x2.shape[0]
+    nb = _lib.query("slim_colsumsq_workspace_bytes", n_chunks, rows, K)
+    ws = _ws(nb, x.device)
+    _lib.call("slim_scaler_row_accum", _p(x2), n_chunks, rows, K, K, batch_per_chunk, _p(scaler_row),
+              int(nsamples_before), _p(ws), ws.numel(), _stream())
+    return scaler_row
+
+
+def gram_accum(x, H, nsamples_before, batch):
+    x = _chk(x, BF16, "x")
+    _chk(H, torch.float32, "H")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    ws = _ws(_lib.query("slim_gram_workspace_bytes", x2.shape[0], K), x.device)
+    _lib.call("slim_gram_accum", _p(x2), x2.shape[0], K, K, _p(H), int(nsamples_before), int(batch), _p(ws),
+              ws.numel(), _stream())
+    return H
+
+
+def shift_zeros(v):
+    v = _chk(v, torch.float32, "x")
+    out = torch.empty_like(v)
+    _lib.call("slim_shift_zeros", _p(v), _p(out), v.numel(), _stream())
+    return out
+
+
+def sqrt(v):
+    v = _chk(v, torch.float32, "x")
+    out = torch.empty_like(v)
+    _lib.call("slim_sqrt_f32", _p(v), _p(out), v.numel(), _stream())
+    return out
+
+
+def any_zero(v):
+    v = _chk(v, torch.float32, "x")
+    flag = torch.empty(1, dtype=torch.int32, device=v.device)
+    _lib.call("slim_any_zero_f32", _p(v), v.numel(), _p(flag), _stream())
+    return bool(flag.item())
+
+
+# ---- N:M mask --------------------------------------------------------------------------------
+def mask_nm(W, s, n, m):
+    """Fused saliency |W| * s and N:M selection; returns a bool [N, K] tensor (True = pruned)."""
+    W = _chk(W, BF16, "W")
+    if s is not None:
+        s = _chk(s, torch.float32, "s")
+        assert s.numel() == W.shape[1]
+    mask = torch.empty(W.shape, dtype=torch.bool, device=W.device)
+    _lib.call("slim_mask_nm", _p(W), _p(s), W.shape[0], W.shape[1], n, m, _p(mask), _stream())
+    return mask
+
+
+def prune_nm_f32(metric, n, m):
+    metric = _chk(metric, torch.float32, "metric")
+    mask = torch.empty(metric.shape, dtype=torch.bool, device=metric.device)
+    _lib.call("slim_prune_nm_f32", _p(metric), metric.shape[0], metric.shape[1], n, m, _p(mask), _stream())
+    return mask
+
+
+# ---- SLiM-Quant ------------------------------------------------------------------------------
+def hist_abs(W, hist=None):
+    W = _chk(W, BF16, "W")
+    acc = hist is not None
+    if hist is None:
+        hist = torch.empty(32768, dtype=torch.int32, device=W.device)
+    _lib.call("slim_hist_abs_bf16", _p(W), W.numel(), _p(hist), int(acc), _stream())
+    return hist
+
+
+def quant_search(hist, num_bins, num_bits):
+    """Returns (alpha 0-d fp32, idx 0-d int32, sf 0-d fp32) device tensors."""
+    dev = hist.device
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    idx = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _ws(_lib.query("slim_quant_search_workspace_bytes", num_bins), dev)
+    _lib.call("slim_quant_search", _p(hist), num_bins, num_bits, _p(out), _p(idx), _p(out[1:]), _p(ws), ws.numel(),
+              _stream())
+    return out[0], idx[0], out[1], ws
+
+
+def absmax_scale(hist, num_bits):
+    out = torch.empty(2, dtype=torch.float32, device=hist.device)
+    _lib.call("slim_absmax_scale", _p(hist), num_bits, _p(out), _p(out[1:]), _stream())
+    return out[0], out[1]
+
+
+def quantize_pt(W, sf, num_bits):
+    W = _chk(W, BF16, "W")
+    sf = _chk(sf, torch.float32, "sf")
+    codes = torch.empty(W.shape, dtype=torch.int8, device=W.device)
+    _lib.call("slim_quantize_pt", _p(W), W.numel(), _p(sf), num_bits, _p(codes), _stream())
+    return codes
+
+
+def dequantize_pt(codes, sf, out_bf16=False):
+    codes = _chk(codes, torch.int8, "codes")
+    sf = _chk(sf, torch.float32, "sf")
+    out = torch.empty(codes.shape, dtype=BF16 if out_bf16 else torch.float32, device=codes.device)
+    _lib.call("slim_dequantize_pt", _p(codes), codes.numel(), _p(sf), _p(out), int(out_bf16), _stream())
+    return out
+
+
+def fake_quant_pt(W, sf, num_bits, want_codes=False):
+    W = _chk(W, BF16, "W")
+    sf = _chk(sf, torch.float32, "sf")
+    out = torch.empty_like(W)
+    codes = torch.empty(W.shape, dtype=torch.int8, device=W.device) if want_codes else None
+    _lib.call("slim_fake_quant_pt", _p(W), W.numel(), _p(sf), num_bits, _p(out), _p(codes), _stream())
+    return (out, codes) if want_codes else out
+
+
+# ---- low-rank fit ----------------------------------------------------------------------------
+def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True):
+    W = _chk(W, BF16, "W")
+    mask = _chk(mask, torch.bool, "mask")
+    N, K = W.shape
+    e32 = torch.empty(N, K, dtype=torch.float32, device=W.device) if want_f32 else None
+    e16 = torch.empty(N, K, dtype=BF16, device=W.device) if want_bf16 else None
+    _lib.call("slim_error_matrix", _p(W), _p(mask), _p(s), _p(sf), num_bits, N, K, _p(e32), _p(e16), _stream())
+    return e32, e16
+
+
+def transpose(x):
+    x = _chk(x, BF16, "x")
+    R, Cc = x.shape
+    out = torch.empty(Cc, R, dtype=BF16, device=x.device)
+    _lib.call("slim_transpose_bf16", _p(x), R, Cc, _p(out), _stream())
+    return out
+
+
+def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False):
+    """C = alpha * A @ Bt.T (+ beta * C32). Returns (C fp32 | None, C bf16 | None, C^T bf16 | None)."""
+    A = _chk(A, BF16, "A")
+    Bt = _chk(Bt, BF16, "Bt")
+    M, Kd = A.shape
+    N = Bt.shape[0]
+    assert Bt.shape[1] == Kd
+    dev = A.device
+    if C32 is None and out_f32:
+        C32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    C16 = torch.empty(M, N, dtype=BF16, device=dev) if out_bf16 else None
+    Ct = torch.empty(N, M, dtype=BF16, device=dev) if out_t else None
+    _lib.call("slim_gemm_nt_bf16", _p(A), Kd, _p(Bt), Kd, M, N, Kd, float(alpha), float(beta), _p(C32), N, _p(C16), N,
+              _p(Ct), M, _stream())
+    return C32, C16, Ct
+
+
+def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, want_info=False):
+    """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info)."""
+    E = _chk(E, BF16, "E")
+    Et = _chk(Et, BF16, "Et")
+    N, K = E.shape
+    l = min(r + oversample, N, K)
+    l -= l % 8
+    if r > l:
+        raise ValueError(f"rank {r} exceeds the usable subspace dimension {l} of a {N}x{K} matrix")
+    dev = E.device
+    U = torch.empty(N, r, dtype=BF16, device=dev)
+    Ut = torch.empty(r, N, dtype=BF16, device=dev)
+    L = torch.empty(K, r, dtype=BF16, device=dev)
+    S = torch.empty(r, dtype=torch.float32, device=dev)
+    info = torch.empty(64, dtype=torch.int32, device=dev)
+    ws = _ws(_lib.query("slim_lowrank_fit_workspace_bytes", N, K, l), dev)
+    _lib.call("slim_lowrank_fit", _p(E), _p(Et), N, K, r, l, n_iter, seed, _p(s), _p(U), _p(Ut), _p(L), _p(S),
+              _p(info), _p(ws), ws.numel(), _stream())
+    return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
+
+
+def lowrank_residual(U, L, W, mask, want_lr=False):
+    U = _chk(U, BF16, "U")
+    L = _chk(L, BF16, "L")
+    W = _chk(W, BF16, "W")
+    mask = _chk(mask, torch.bool, "mask")
+    N, K = W.shape
+    r = U.shape[1]
+    Wn = torch.empty_like(W)
+    LR = torch.empty_like(W) if want_lr else None
+    _lib.call("slim_lowrank_residual", _p(U), _p(L), N, K, r, _p(W), _p(mask), _p(Wn), _p(LR), _stream())
+    return (Wn, LR) if want_lr else Wn
+
+
+def residual_weight(W, LR, mask, want_hist=False):
+    W = _chk(W, BF16, "W")
+    LR = _chk(LR, BF16, "LR")
+    mask = _chk(mask, torch.bool, "mask")
+    Wn = torch.empty_like(W)
+    hist = torch.empty(32768, dtype=torch.int32, device=W.device) if want_hist else None
+    _lib.call("slim_residual_weight", _p(W), _p(LR), _p(mask), W.numel(), _p(Wn), _p(hist), _stream())
+    return (Wn, hist) if want_hist else Wn
+
+
+def randn_bf16(shape, seed, device):
+    out = torch.empty(shape, dtype=BF16, device=device)
+    _lib.call("slim_randn_bf16", _p(out), out.numel(), seed, _stream())
+    return out
+
+
+# ---- group quantisation ------------------------------------------------------------------------
+def group_absmax(x, block):
+    x = _chk(x, BF16, "x")
+    M, N = x.shape
+    assert M % block == 0 and N % block == 0, "Input matrix size is not divisible by block size"
+    al = torch.empty(M // block, N, dtype=BF16, device=x.device)
+    _lib.call("slim_group_absmax", _p(x), M, N, block, _p(al), _stream())
+    return al
+
+
+def group_quantize(x, alphas, bits):
+    x = _chk(x, BF16, "x")
+    alphas = _chk(alphas, BF16, "alphas")
+    M, N = x.shape
+    block = M // alphas.shape[0]
+    codes = torch.empty(M, N, dtype=torch.int8, device=x.device)
+    _lib.call("slim_group_quantize", _p(x), _p(alphas), M, N, block, bits, _p(codes), _stream())
+    return codes
+
+
+def group_dequantize(codes, alphas, bits):
+    codes = _chk(codes, torch.int8, "codes")
+    alphas = _chk(alphas, BF16, "alphas")
+    M, N = codes.shape
+    block = M // alphas.shape[0]
+    out = torch.empty(M, N, dtype=BF16, device=codes.device)
+    _lib.call("slim_group_dequantize", _p(codes), _p(alphas), M, N, block, bits, _p(out), _stream())
+    return out
+
+
+def group_fake_quant(x, block, bits, want_alphas=False):
+    x = _chk(x, BF16, "x")
+    M, N = x.shape
+    assert M % block == 0 and N % block == 0, "Input matrix size is not divisible by block size"
+    out = torch.empty_like(x)
+    al = torch.empty(M // block, N, dtype=BF16, device=x.device) if want_alphas else None
+    _lib.call("slim_group_fake_quant", _p(x), M, N, block, bits, _p(out), _p(al), None, _stream())
+    return (out, al) if want_alphas else out
