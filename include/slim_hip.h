@@ -28,6 +28,13 @@ extern "C" {
 int slim_abi_version(void);
 const char* slim_last_error(void); /* host string, valid until the next failing call on this thread */
 
+/* Optional timing of the library's own launches: slim_profile_enable(1) starts recording a HIP event
+ * pair on the launch stream around each kernel family, slim_profile_summary writes
+ * "name count total_ms" lines into a HOST buffer (it waits for the recorded events), and
+ * slim_profile_enable(0) stops and clears.  No counterpart in the reference. */
+int slim_profile_enable(int on);
+int slim_profile_summary(char* buf_host, int64_t buflen);
+
 /* ---- (1) calibration statistics -------------------------------------------------------- */
 
 /* WrappedGPT.add_batch, slim/layerwrapper.py:25-41, for `n_chunks` consecutive add_batch calls
@@ -151,6 +158,18 @@ int slim_group_dequantize(const int8_t* codes, const void* alphas_bf16, int64_t 
  * quantization.py:313-317); alphas_bf16 and codes may be NULL. */
 int slim_group_fake_quant(const void* x_bf16, int64_t M, int64_t N, int block, int bits, void* out_bf16,
                           void* alphas_bf16, int8_t* codes, void* stream);
+
+/* ---- (5) activation fake-quantisation of the input hooks ------------------------------------------ */
+
+/* 8-bit branch of input_quantization_pre_hook, slim/quantization/quantization.py:286-290: per-tensor
+ * abs-max, e4m3fn if max < 488 else e5m2, every intermediate rounded to bf16 as the reference does.
+ * absmax_scratch: one uint32 of device scratch.  out may alias x. */
+int slim_input_fake_quant_fp8(const void* x_bf16, int64_t numel, void* out_bf16, uint32_t* absmax_scratch,
+                              void* stream);
+/* Quantizer.quantize_input + dequantize_input (symmetric), quantization.py:219-263: x viewed as
+ * [n_groups, group]; per-group abs-max scale, round-half-even, clamp, dequantise; bf16 in, bf16 out. */
+int slim_input_fake_quant_int(const void* x_bf16, int64_t n_groups, int group, int num_bits, float eps,
+                              void* out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

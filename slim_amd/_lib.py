@@ -15,6 +15,8 @@ vp, i64, i32, f32, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint32
 PROTOTYPES = {
     "slim_abi_version": (i32, []),
     "slim_last_error": (C.c_char_p, []),
+    "slim_profile_enable": (i32, [i32]),
+    "slim_profile_summary": (i32, [C.c_char_p, i64]),
     "slim_colsumsq_workspace_bytes": (i64, [i64, i64, i64]),
     "slim_scaler_row_accum": (i32, [vp, i64, i64, i64, i64, i64, vp, i64, vp, i64, vp]),
     "slim_gram_workspace_bytes": (i64, [i64, i64]),
@@ -45,6 +47,8 @@ PROTOTYPES = {
     "slim_group_quantize": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
     "slim_group_dequantize": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
     "slim_group_fake_quant": (i32, [vp, i64, i64, i32, i32, vp, vp, vp, vp]),
+    "slim_input_fake_quant_fp8": (i32, [vp, i64, vp, vp, vp]),
+    "slim_input_fake_quant_int": (i32, [vp, i64, i32, i32, f32, vp, vp]),
 }
 
 ERR_INVALID, ERR_LAUNCH, ERR_UNSUPPORTED, ERR_SOLVER = -1, -2, -3, -4
@@ -95,3 +99,19 @@ def call(name, *args):
 def query(name, *args):
     """Call an entry point that returns a value (workspace sizes, version)."""
     return getattr(load(), name)(*args)
+
+
+def profile_enable(on=True):
+    call("slim_profile_enable", int(bool(on)))
+
+
+def profile_summary():
+    """{scope name: dict(count, ms, bytes, flops)} of the launches recorded since profile_enable; bytes and
+    flops are the algorithmic traffic / arithmetic the library attributes to those launches."""
+    buf = C.create_string_buffer(1 << 16)
+    call("slim_profile_summary", buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms, nbytes, flops = line.split()
+        out[name] = dict(count=int(cnt), ms=float(ms), bytes=float(nbytes), flops=float(flops))
+    return out

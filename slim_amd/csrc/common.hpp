@@ -13,6 +13,24 @@ void slim_set_error(const char* fmt, ...);
 // Raise a kernel's dynamic-LDS limit above 64 KiB once per (kernel, device).
 hipError_t slim_allow_dynamic_lds(const void* func, int bytes);
 
+// Optional per-launch timing (slim_profile_enable): an RAII scope records a HIP event pair on the
+// launch stream around the kernels it encloses.
+int slim_prof_begin(const char* name, hipStream_t st, double bytes = 0.0, double flops = 0.0);
+void slim_prof_end(int token, hipStream_t st);
+extern bool g_slim_prof_on;
+struct SlimProfScope {
+    int token;
+    hipStream_t st;
+    SlimProfScope(const char* name, hipStream_t s, double bytes = 0.0, double flops = 0.0)
+        : token(g_slim_prof_on ? slim_prof_begin(name, s, bytes, flops) : -1), st(s) {}
+    ~SlimProfScope() {
+        if (token >= 0) slim_prof_end(token, st);
+    }
+};
+// bytes / flops: the ALGORITHMIC traffic or arithmetic of the enclosed launches (inputs read once,
+// outputs written once), accumulated per scope name for roofline reporting
+#define SLIM_PROF(name, stream, ...) SlimProfScope prof_scope__(name, (hipStream_t)(stream), ##__VA_ARGS__)
+
 #define SLIM_REQUIRE(cond, ...)              \
     do {                                     \
         if (!(cond)) {                       \

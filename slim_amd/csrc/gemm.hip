@@ -177,6 +177,10 @@ static int gemm_launch(const GemmArgs& g, void* stream) {
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
     const int lds_bytes = 4 * BM * LDS_STRIDE * (int)sizeof(bf16_t);
     SLIM_HIP(slim_allow_dynamic_lds((const void*)gemm_nt_kernel, lds_bytes));
+    SLIM_PROF(g.Wn ? "gemm_nt_residual" : "gemm_nt", stream,
+              2.0 * ((double)g.M + g.N) * g.Kd + (double)g.M * g.N * ((g.C32 ? 4.0 : 0.0) + (g.C16 ? 2.0 : 0.0) +
+                                                                      (g.Ct16 ? 2.0 : 0.0) + (g.Wn ? 5.0 : 0.0)),
+              2.0 * g.M * g.N * g.Kd);
     gemm_nt_kernel<<<(unsigned)tiles, 256, lds_bytes, (hipStream_t)stream>>>(g);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 extern "C" int slim_transpose_bf16(const void* in, int64_t R, int64_t C, void* out, void* stream) {
     SLIM_REQUIRE(in && out && R > 0 && C > 0, "slim_transpose_bf16: bad arguments");
     SLIM_REQUIRE(ceil_div64(R, 64) <= 65535, "slim_transpose_bf16: too many rows");
+    SLIM_PROF("transpose", stream, 4.0 * R * C);
     dim3 grid((unsigned)ceil_div64(C, 64), (unsigned)ceil_div64(R, 64));
     transpose_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)in, R, C, (bf16_t*)out);
     SLIM_LAUNCH_CHECK();

@@ -118,6 +118,7 @@ static int gq_launch(const char* who, const void* x, const int8_t* codes_in, con
     SLIM_REQUIRE(bits >= 2 && bits <= 8, "%s: bits must be in [2, 8]", who);
     SLIM_REQUIRE(M / block <= 65535, "%s: too many row groups", who);
     const float maxq = (float)((1 << (bits - 1)) - 1);
+    SLIM_PROF("group_quant", stream, ((x ? 2.0 : 1.0) + (codes_out ? 1.0 : 0.0) + (deq_out ? 2.0 : 0.0)) * M * N);
     dim3 grid((unsigned)ceil_div64(N, 128), (unsigned)(M / block));
     group_quant_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, codes_in, (const bf16_t*)alphas_in, M, N,
                                                              block, maxq, (bf16_t*)alphas_out, codes_out,

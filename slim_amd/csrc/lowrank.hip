@@ -219,6 +219,7 @@ static int cholesky_qr(rb_handle h, const bf16_t* X, const bf16_t* Xt, bf16_t* Q
     CHK(slim_gemm_nt_bf16(Xt, rows, Xt, rows, l, l, (int)rows, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
     ridge_kernel<<<1, 256, 0, st>>>(w.G, l, 1e-6f);
     SLIM_LAUNCH_CHECK();
+    int solver_tok = g_slim_prof_on ? slim_prof_begin("solver_potrf_trtri", st, 0.0, (double)l * l * l) : -1;
     if (g_solver.potrf(h, RB_FILL_UPPER, l, w.G, l, info) != 0) {
         slim_set_error("rocsolver_spotrf failed");
         return SLIM_ERR_SOLVER;
@@ -227,6 +228,7 @@ static int cholesky_qr(rb_handle h, const bf16_t* X, const bf16_t* Xt, bf16_t* Q
         slim_set_error("rocsolver_strtri failed");
         return SLIM_ERR_SOLVER;
     }
+    if (solver_tok >= 0) slim_prof_end(solver_tok, st);
     dim3 grid((unsigned)((l + 255) / 256), (unsigned)l);
     tri_to_bf16_kernel<<<grid, 256, 0, st>>>(w.G, l, w.T16);
     SLIM_LAUNCH_CHECK();
@@ -270,11 +272,13 @@ extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_
     // Rayleigh-Ritz: B = Q^T E (kept as B^T = Z [K, l]); M = B B^T = W diag(S^2) W^T
     CHK(slim_gemm_nt_bf16(w.A1T, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B0T, K, w.B0, l, stream));
     CHK(slim_gemm_nt_bf16(w.B0T, K, w.B0T, K, l, l, (int)K, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
+    int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l) : -1;
     if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, w.evals, w.ework, w.info + ninfo) != 0) {
         slim_set_error("rocsolver_ssyevd failed");
         return SLIM_ERR_SOLVER;
     }
     ninfo += 1;
+    if (syevd_tok >= 0) slim_prof_end(syevd_tok, st);
     {
         dim3 grid((unsigned)((l + 255) / 256), (unsigned)r);
         top_eigvecs_kernel<<<grid, 256, 0, st>>>(w.G, w.evals, l, r, w.T16, S);

@@ -203,6 +203,7 @@ static int launch_mask(const void* src, bool from_bf16, const float* s, int64_t 
     SLIM_REQUIRE(K % 8 == 0, "slim_mask_nm: K must be a multiple of 8");
     SLIM_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)mask % 8) == 0 && (!s || ((uintptr_t)s % 16) == 0),
                  "slim_mask_nm: pointers must be 16-byte aligned");
+    SLIM_PROF("mask_nm", stream, (from_bf16 ? 3.0 : 5.0) * N * K + (s ? 4.0 * K : 0.0));
     std::call_once(g_lut_once, build_luts);
     LutArg la;
     for (int i = 0; i < 736; ++i) la.v[i] = i < 729 ? g_lut[n - 1][i] : 0;

@@ -55,6 +55,7 @@ extern "C" int slim_hist_abs_bf16(const void* W, int64_t numel, uint32_t* hist, 
     hipStream_t st = (hipStream_t)stream;
     SLIM_HIP(slim_allow_dynamic_lds((const void*)hist_bf16_kernel, HIST_BINS * 4));
     if (!accumulate) SLIM_HIP(hipMemsetAsync(hist, 0, HIST_BINS * sizeof(uint32_t), st));
+    SLIM_PROF("hist_bf16", stream, 2.0 * numel);
     int64_t blocks = ceil_div64(numel >> 3, 1024 * 4);
     if (blocks < 1) blocks = 1;
     if (blocks > 256) blocks = 256;
@@ -282,6 +283,7 @@ extern "C" int slim_quant_search(const uint32_t* hist, int num_bins, int num_bit
     SLIM_REQUIRE(workspace_bytes >= slim_quant_search_workspace_bytes(num_bins), "slim_quant_search: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     SLIM_HIP(slim_allow_dynamic_lds((const void*)rebin_kernel, MAX_SEARCH_BINS * 4));
+    SLIM_PROF("quant_search", stream);
     float* ws = (float*)workspace;
     rebin_kernel<<<1, 1024, (size_t)num_bins * 4, st>>>(hist, num_bins, ws);
     SLIM_LAUNCH_CHECK();
@@ -356,6 +358,7 @@ extern "C" int slim_quantize_pt(const void* W, int64_t numel, const float* sf, i
     SLIM_REQUIRE(W && sf && codes && numel > 0, "slim_quantize_pt: bad arguments");
     SLIM_REQUIRE(num_bits >= 2 && num_bits <= 8, "slim_quantize_pt: num_bits must be in [2, 8]");
     SLIM_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)codes % 8) == 0, "slim_quantize_pt: misaligned pointer");
+    SLIM_PROF("quantize_pt", stream, 3.0 * numel);
     int64_t blocks = ceil_div64(numel >> 3, 256);
     blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
     quantize_pt_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, numel, sf, num_bits, codes);
@@ -424,6 +427,7 @@ extern "C" int slim_fake_quant_pt(const void* W, int64_t numel, const float* sf,
     SLIM_REQUIRE(num_bits >= 2 && num_bits <= 8, "slim_fake_quant_pt: num_bits must be in [2, 8]");
     SLIM_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)out_bf16 % 16) == 0 && (!codes || ((uintptr_t)codes % 8) == 0),
                  "slim_fake_quant_pt: misaligned pointer");
+    SLIM_PROF("fake_quant_pt", stream, (codes ? 5.0 : 4.0) * numel);
     int64_t blocks = ceil_div64(numel >> 3, 256);
     blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
     fake_quant_pt_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, numel, sf, num_bits,
@@ -489,6 +493,7 @@ extern "C" int slim_error_matrix(const void* W, const uint8_t* mask, const float
     SLIM_REQUIRE(W && mask && (E_f32 || E_bf16) && N > 0 && K > 0, "slim_error_matrix: bad arguments");
     SLIM_REQUIRE(K % 8 == 0, "slim_error_matrix: K must be a multiple of 8");
     SLIM_REQUIRE(!sf || (num_bits >= 2 && num_bits <= 8), "slim_error_matrix: num_bits must be in [2, 8]");
+    SLIM_PROF("error_matrix", stream, (3.0 + (E_f32 ? 4.0 : 0.0) + (E_bf16 ? 2.0 : 0.0)) * N * K);
     int64_t blocks = ceil_div64(N * (K >> 3), 256);
     blocks = blocks > 8192 ? 8192 : blocks;
     error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K,
@@ -546,6 +551,7 @@ extern "C" int slim_residual_weight(const void* W, const void* LR, const uint8_t
     SLIM_REQUIRE(W && LR && mask && out && numel > 0, "slim_residual_weight: bad arguments");
     SLIM_REQUIRE(numel % 8 == 0, "slim_residual_weight: numel must be a multiple of 8");
     hipStream_t st = (hipStream_t)stream;
+    SLIM_PROF("residual_weight", stream, 7.0 * numel);
     int64_t blocks = ceil_div64(numel >> 3, 1024 * 2);
     blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
     if (hist) {

@@ -91,6 +91,7 @@ extern "C" int slim_scaler_row_accum(const void* x, int64_t n_chunks, int64_t ro
     const int slabs = (int)ceil_div64(rows_per_chunk, SLAB_ROWS);
     SLIM_REQUIRE(n_chunks <= 65535 && slabs <= 65535, "slim_scaler_row_accum: too many chunks/slabs for one launch");
     hipStream_t st = (hipStream_t)stream;
+    SLIM_PROF("colsumsq", stream, 2.0 * n_chunks * rows_per_chunk * K);
     dim3 grid((unsigned)ceil_div64(K, 256 * 8), (unsigned)slabs, (unsigned)n_chunks);
     colsumsq_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows_per_chunk, K, ld, (float*)workspace, slabs);
     SLIM_LAUNCH_CHECK();

@@ -276,3 +276,21 @@ def group_fake_quant(x, block, bits, want_alphas=False):
     al = torch.empty(M // block, N, dtype=BF16, device=x.device) if want_alphas else None
     _lib.call("slim_group_fake_quant", _p(x), M, N, block, bits, _p(out), _p(al), None, _stream())
     return (out, al) if want_alphas else out
+
+
+# ---- activation fake-quantisation --------------------------------------------------------------
+def input_fake_quant_fp8(x):
+    x = _chk(x, BF16, "x")
+    out = torch.empty_like(x)
+    scratch = torch.empty(1, dtype=torch.int32, device=x.device)
+    _lib.call("slim_input_fake_quant_fp8", _p(x), x.numel(), _p(out), _p(scratch), _stream())
+    return out
+
+
+def input_fake_quant_int(x, num_bits, group_size, eps=1e-4):
+    x = _chk(x, BF16, "x")
+    group = x.shape[-1] if group_size == -1 else group_size
+    assert x.numel() % group == 0
+    out = torch.empty_like(x)
+    _lib.call("slim_input_fake_quant_int", _p(x), x.numel() // group, group, num_bits, float(eps), _p(out), _stream())
+    return out

@@ -1,0 +1,51 @@
+"""Multi-GPU partitioning of the compression path: one process per GPU, torch.distributed (RCCL on the
+GPUs, gloo in CPU tests).  The reference has no distributed code; this is new design.
+
+Within one decoder block the linear layers are independent once their calibration statistics exist, so
+they are assigned to ranks by cost; the owner compresses a linear and broadcasts the result (weight,
+adapters, scale), because every rank needs the whole compressed block for the next forward pass."""
+import torch
+import torch.distributed as dist
+
+
+def partition_by_cost(costs, world_size):
+    """Longest-processing-time-first: owner[i] = rank that compresses item i.  Deterministic on every rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world_size
+    owner = [0] * len(costs)
+    for i in order:
+        r = min(range(world_size), key=lambda j: (load[j], j))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+def linear_cost(n, k):
+    """Relative cost of compressing an n x k linear: dominated by passes over the n*k matrix."""
+    return float(n) * float(k)
+
+
+def exchange_linear(lin, owner, rank, shapes, device, group=None):
+    """Broadcast one compressed linear from its owner.  shapes = (N, K, r).  Non-owners allocate receive
+    buffers; afterwards every rank holds weight.data [N, K], lora_left [K, r], lora_right [r, N] and
+    scaling_factor (1, 1)."""
+    N, K, r = shapes
+    dt = lin.weight.dtype
+    if owner != rank:
+        lin.weight.data = torch.empty(N, K, dtype=dt, device=device)
+        lin.lora_left = torch.nn.Parameter(torch.empty(K, r, dtype=dt, device=device), requires_grad=False)
+        lin.lora_right = torch.nn.Parameter(torch.empty(r, N, dtype=dt, device=device), requires_grad=False)
+        lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=device)
+    for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data, lin.scaling_factor):
+        dist.broadcast(t, src=owner, group=group)
+    return lin
+
+
+def gather_sample_stats(local_sumsq, group=None):
+    """All-gather per-sample column sums of squares ([n_local, K] fp32 each) into sample order
+    [n_local * world, K], so that every rank can apply the scaler_row recurrence in the same order as a
+    single-GPU run.  Rank r is expected to hold samples r * n_local ... (r + 1) * n_local - 1."""
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(local_sumsq) for _ in range(world)]
+    dist.all_gather(parts, local_sumsq.contiguous(), group=group)
+    return torch.cat(parts, 0)

@@ -1,0 +1,274 @@
+"""Public entry point and per-block driver (mirror of reference slim/prune.py:
+prune_and_quantize :1419-1709, prune_wanda :148-372, prepare_calibration_input :26-78).
+
+Differences in mechanism, not in contract: the calibration activations stay resident in HBM for the
+whole run (the reference shuttles every sample CPU<->GPU twice per block), the block forwards may be
+batched while the statistics keep the reference's one-sample-at-a-time accumulation order, and every
+per-linear step (statistics, mask, scale search, quantisation, low-rank fit) is a HIP kernel.
+"""
+import torch
+import torch.nn as nn
+import tqdm.auto as tqdm
+
+from . import ops
+from .data import get_loaders
+from .layerwrapper import WrappedGPT
+from .lora import add_lora
+from .quantization.quantization import Quantizer as AutoQuantizer, QuantizedMatmul
+from .utils import get_layers_list, find_layers
+
+# samples per block forward during calibration (statistics are accumulated per sample regardless)
+CALIBRATION_BATCH = 1
+# leave compressed blocks on the accelerator instead of returning them to the CPU like the reference
+KEEP_ON_DEVICE = False
+# optional callable(i, name, module, wrapped) invoked after each linear is compressed (tests, tracing)
+LAYER_CALLBACK = None
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("slim_amd needs a ROCm GPU: the compression path has no CPU implementation")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def prepare_calibration_input(model, dataloader, nsamples=128, device=None):
+    """Capture the inputs of decoder block 0 for every calibration sample (prune.py:26-78).
+
+    Returns (inps, outs, kwargs): inps/outs are [nsamples, seqlen, hidden] in the model dtype, held on
+    `device` (the reference keeps them on the CPU), kwargs are the block's keyword arguments."""
+    use_cache = model.config.use_cache
+    model.config.use_cache = False
+    layers = get_layers_list(model)
+    dtype = next(iter(model.parameters())).dtype
+    device = device or _device()
+    inps = torch.zeros((nsamples, model.config.max_position_embeddings, model.config.hidden_size), dtype=dtype,
+                       device=device)
+    inps.requires_grad = False
+    cache = {"i": 0, "attention_mask": None, "position_ids": None}
+
+    class Catcher(nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, inp, **kwargs):
+            inps[cache["i"]] = inp.to(device)
+            cache["i"] += 1
+            for key in kwargs:
+                cache[key] = kwargs[key]
+            raise ValueError
+
+    layers[0] = Catcher(layers[0])
+    model_device = next(iter(model.parameters())).device
+    for batch in dataloader:
+        try:
+            model(batch[0].to(model_device))
+        except ValueError:
+            pass
+    layers[0] = layers[0].module
+    outs = torch.zeros_like(inps)
+    model.config.use_cache = use_cache
+    del cache["i"]
+    return inps, outs, cache
+
+
+def _to_device(kwargs, device):
+    out = {}
+    for key, v in kwargs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.to(device)
+        elif isinstance(v, tuple):
+            v = tuple(k.to(device) if isinstance(k, torch.Tensor) else k for k in v)
+        out[key] = v
+    return out
+
+
+def add_lora_hook(module, input, output):
+    """Forward hook adding the adapter path to the Linear's output in place (prune.py:303-321)."""
+    if hasattr(module, "lora_quantizer"):
+        xl = QuantizedMatmul.apply(input[0].to(module.lora_left.dtype) / torch.sqrt(module.lora_rank),
+                                   module.lora_left, module.lora_quantizer)
+        xlr = QuantizedMatmul.apply(xl / torch.sqrt(module.lora_rank), module.lora_right, module.lora_quantizer)
+        output += xlr
+    else:
+        output += torch.matmul(
+            torch.matmul(input[0].to(module.lora_left.dtype), module.lora_left / torch.sqrt(module.lora_rank)),
+            module.lora_right / torch.sqrt(module.lora_rank))
+
+
+def _run_block(layer, src, dst, kwargs, batch):
+    n = src.shape[0]
+    with torch.no_grad():
+        for j in range(0, n, batch):
+            out = layer(src[j:j + batch], **kwargs)
+            if isinstance(out, (tuple, list)):      # older decoder layers return (hidden_states, ...)
+                out = out[0]
+            dst[j:j + batch] = out
+
+
+def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quantize_weight=False, bitwidth=4,
+                slim_quant=False, tiled_weight_quantization=False, weight_tile_size=256, shift_zero_metrics=True,
+                lora_rank=0., slim_lora=True, prune_lora=False, quantize_lora=False, lora_tile_size=256,
+                separate_lora=True, nsamples=128, seed=0, calibration_dataset="c4", pad_lora=False,
+                quantize_first=True, scale_important_weights=False):
+    """Wanda N:M pruning + weight quantisation + low-rank adapters, block by block (prune.py:148-372)."""
+    if prune_n == 0:
+        raise NotImplementedError("unstructured Wanda pruning is not implemented (only N:M with M = 4)")
+    if tiled_weight_quantization and quantize_weight:
+        raise NotImplementedError("tiled weight quantisation is not implemented in the Wanda driver")
+    if scale_important_weights:
+        raise NotImplementedError("scale_important_weights is not implemented")
+    dev = _device()
+    use_cache = model.config.use_cache
+    model.config.use_cache = False
+
+    dataloader, _ = get_loaders(calibration_dataset, nsamples=nsamples, seed=seed,
+                                seqlen=model.config.max_position_embeddings, tokenizer=tokenizer)
+    with torch.no_grad():
+        inps, outs, kwargs = prepare_calibration_input(model, dataloader, nsamples, device=dev)
+    kwargs = _to_device(kwargs, dev)
+
+    quantizer = AutoQuantizer("weight", num_bits=bitwidth, slim_quant=slim_quant,
+                              block_quantization=tiled_weight_quantization,
+                              block_dim=weight_tile_size) if quantize_weight else None
+    layers = get_layers_list(model)
+    progress_bar = tqdm.tqdm(range(len(layers)))
+    for i in progress_bar:
+        progress_bar.set_description(f"Layer {i} - Gathering data")
+        layer = layers[i].to(dev)
+        subset = find_layers(layer)
+        wrapped_layers = {name: WrappedGPT(subset[name]) for name in subset}
+
+        def add_batch(name):
+            def tmp(_, inp, out):
+                wrapped_layers[name].add_batch(inp[0].data, out.data, per_sample=True)
+            return tmp
+
+        handles = [subset[name].register_forward_hook(add_batch(name)) for name in wrapped_layers]
+        _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
+        for h in handles:
+            h.remove()
+
+        for name in subset:
+            progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}")
+            lin, wrapped = subset[name], wrapped_layers[name]
+            if shift_zero_metrics:
+                wrapped.scaler_row = ops.shift_zeros(wrapped.scaler_row)
+            if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
+                W_mask = lin.weight.mask.to(dev)
+                del lin.weight.mask
+            else:
+                W_mask = ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), prune_n, prune_m)
+
+            if lora_rank > 0.:
+                tile = lora_tile_size if (quantize_lora or pad_lora) else None
+                add_lora(lin, W_mask=W_mask, rank_ratio=lora_rank, slim_lora=slim_lora, activations=wrapped,
+                         quantizer=quantizer, prune_lora=prune_lora, separate_lora=separate_lora, lora_tile_size=tile,
+                         quantize_first=quantize_first, scale_important_weights=scale_important_weights)
+                if quantizer is not None:
+                    lin.scaling_factor = None if tiled_weight_quantization else quantizer.scaling_factor
+                if separate_lora:
+                    lin.lora_rank = torch.tensor(lin.lora_left.shape[1])
+                    lin.lora_left = torch.nn.Parameter(lin.lora_left * torch.sqrt(lin.lora_rank))
+                    lin.lora_right = torch.nn.Parameter(lin.lora_right * torch.sqrt(lin.lora_rank))
+                    lin.register_forward_hook(add_lora_hook)
+            else:
+                # prune.py:330-357, quantize_first branch: quantise the dense weight, then zero the mask
+                if not quantize_first:
+                    raise NotImplementedError("quantize_first=False is not implemented")
+                if quantizer is not None:
+                    codes = quantizer.quantize_weight(lin.weight.data)
+                    lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
+                    lin.scaling_factor = quantizer.scaling_factor
+                lin.weight.data[W_mask] = 0
+            if LAYER_CALLBACK is not None:
+                LAYER_CALLBACK(i, name, lin, wrapped)
+
+        progress_bar.set_description(f"Layer {i} - Evaluating Output")
+        _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
+        inps, outs = outs, inps
+        if not KEEP_ON_DEVICE:
+            layers[i] = layer.cpu()
+        del layer
+
+    model.config.use_cache = use_cache
+    torch.cuda.empty_cache()
+
+
+def prune_and_quantize(model, tokenizer, bitwidth=4, slim_quant=True, weight_tiled_quantization=False,
+                       weight_tile_size=256, prune_method="wanda", sparsity_ratio=0.5, sparsity_type="2:4",
+                       quantize_weight=False, nsamples=128, shift_zero_metrics=True, lora_rank=0., slim_lora=True,
+                       prune_lora=False, quantize_lora=False, lora_tile_size=256, separate_lora=True, seed=0,
+                       joint_pq_mixing_factor=2.1, calibration_dataset="c4", pad_lora=False,
+                       scale_important_weights=False, mask_checkpoint=None, quantize_first=True):
+    """Prune, quantise and add low-rank adapters to `model` in place; returns None (prune.py:1419-1709).
+
+    Same signature, flag validation and error behaviour as the reference.  The Wanda / SLiM path
+    ("wanda", and "maskllm" when the weights already carry a `.mask`) is implemented; the alternative
+    baselines of the reference (magnitude, sparsegpt, joint_pq, pruner_zero, prune_gblm) and the dense
+    quantisation-only mode raise NotImplementedError after the reference's own argument checks."""
+    if sparsity_ratio == 0. or sparsity_type == "dense":
+        if quantize_weight:
+            print("Quantizing the dense model:")
+            if lora_rank > 0:
+                raise NotImplementedError("LoRA approximation not implemented for quantization only - "
+                                          "Please use pruning with low sparsity ratio for quantization only.")
+            raise NotImplementedError("dense quantization-only mode is not implemented in slim_amd")
+        print("Using original dense model.")
+        return
+    print("Sparsity Ratio: ", sparsity_ratio)
+    print("Pruning Structure: ", sparsity_type)
+    prune_n, prune_m = 0, 0
+    if sparsity_type != "unstructured":
+        prune_n, prune_m = map(int, sparsity_type.split(":"))
+        prune_n = prune_m - prune_n
+        assert sparsity_ratio == prune_n / prune_m, \
+            f"Sparsity ratio must be {prune_n / prune_m} for structured N:M sparsity"
+    if prune_method in ["wanda", "maskllm", "pruner_zero", "prune_gblm"]:
+        if quantize_weight:
+            method = "SLiM-Quant" if slim_quant else ("Tiled Group AbsMax" if weight_tiled_quantization else "AbsMax")
+            print(f"Pruning the model with {prune_method} and quantizing the weights using {method}.")
+        else:
+            print(f"Pruning the model with {prune_method}.")
+        if lora_rank > 0:
+            print(f"Adding {'SLiM' if slim_lora else 'Naive'}-LoRA approximation with rank ratio {lora_rank}.")
+        if prune_lora and not (prune_n == 2 and prune_m == 4):
+            raise NotImplementedError("Pruning LoRA is only supported for 2:4 sparsity ratio")
+        if prune_method == "maskllm":
+            assert mask_checkpoint is not None, "Mask checkpoint must be provided for MaskLLM pruning"
+            assert prune_n == 2 and prune_m == 4, "MaskLLM pruning only supports 2:4 sparsity ratio"
+            if not any(hasattr(p, "mask") for p in model.parameters()):
+                raise NotImplementedError("downloading MaskLLM masks needs network access; attach the masks as "
+                                          "`param.mask` (True = pruned) before calling")
+        if prune_method in ("pruner_zero", "prune_gblm"):
+            raise NotImplementedError(f"Pruning method {prune_method} is not implemented in slim_amd")
+        prune_wanda(model, tokenizer, sparsity_ratio, prune_n, prune_m, quantize_weight, bitwidth, slim_quant,
+                    weight_tiled_quantization, weight_tile_size, shift_zero_metrics, lora_rank, slim_lora, prune_lora,
+                    quantize_lora, lora_tile_size, separate_lora, nsamples, seed, calibration_dataset, pad_lora,
+                    scale_important_weights=scale_important_weights, quantize_first=quantize_first)
+    elif prune_method == "magnitude":
+        if scale_important_weights and quantize_weight:
+            raise NotImplementedError("Scaling important weights not implemented for magnitude pruning and "
+                                      "quantization")
+        if lora_rank > 0:
+            raise NotImplementedError("LoRA approximation not implemented for magnitude pruning")
+        raise NotImplementedError("Pruning method magnitude is not implemented in slim_amd")
+    elif prune_method == "sparsegpt":
+        if scale_important_weights and quantize_weight:
+            raise NotImplementedError("Scaling important weights not implemented for magnitude pruning and "
+                                      "quantization")
+        if lora_rank > 0:
+            raise NotImplementedError("LoRA approximation not implemented for SparseGPT")
+        if slim_quant:
+            raise NotImplementedError("SparseGPT can only support OPTQ (GPTQ) quantization")
+        raise NotImplementedError("Pruning method sparsegpt is not implemented in slim_amd")
+    elif prune_method == "joint_pq":
+        if weight_tiled_quantization is False:
+            raise NotImplementedError("Joint pruning and quantization only supports block quantization")
+        if slim_quant:
+            raise NotImplementedError("Joint pruning and quantization only supports AbsMax")
+        if quantize_weight is False:
+            raise NotImplementedError("Joint pruning and quantization requires quantizing weights")
+        raise NotImplementedError("Pruning method joint_pq is not implemented in slim_amd")
+    else:
+        raise NotImplementedError(f"Pruning method {prune_method} not implemented")

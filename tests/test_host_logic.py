@@ -1,0 +1,96 @@
+"""Host-side logic that needs no GPU: dispatcher validation and error behaviour (against the
+reference's recorded behaviour), rank rule, synthetic loaders, the perplexity harness, module aliases."""
+import pytest
+import torch
+
+from oracle import slim_oracle as O
+
+
+def test_dispatcher_errors_match_reference(golden):
+    import slim_amd.prune as P
+    g = golden("g10_dispatch_errors")
+    for combo, err in zip(g["combos"].tolist(), g["errors"].tolist()):
+        kw = dict(bitwidth=4, slim_quant=False)
+        kw.update(dict(eval(combo)))
+        with pytest.raises({"NotImplementedError": NotImplementedError, "AssertionError": AssertionError}[err]):
+            P.prune_and_quantize(None, None, **kw)
+
+
+def test_dense_noop_and_unknown_method():
+    import slim_amd.prune as P
+    assert P.prune_and_quantize(None, None, sparsity_type="dense") is None
+    with pytest.raises(NotImplementedError, match="nonsense"):
+        P.prune_and_quantize(None, None, prune_method="nonsense")
+    with pytest.raises(AssertionError, match="Sparsity ratio must be"):
+        P.prune_and_quantize(None, None, sparsity_type="2:4", sparsity_ratio=0.25)
+
+
+def test_signatures_match_reference_api():
+    import inspect
+    import slim.prune, slim.lora, slim.eval, slim.utils, slim.layerwrapper      # noqa: E401
+    import slim.quantization.quantization as Q
+    sig = inspect.signature(slim.prune.prune_and_quantize)
+    expect = ["model", "tokenizer", "bitwidth", "slim_quant", "weight_tiled_quantization", "weight_tile_size",
+              "prune_method", "sparsity_ratio", "sparsity_type", "quantize_weight", "nsamples", "shift_zero_metrics",
+              "lora_rank", "slim_lora", "prune_lora", "quantize_lora", "lora_tile_size", "separate_lora", "seed",
+              "joint_pq_mixing_factor", "calibration_dataset", "pad_lora", "scale_important_weights",
+              "mask_checkpoint", "quantize_first"]
+    assert list(sig.parameters) == expect
+    assert sig.parameters["quantize_weight"].default is False and sig.parameters["lora_tile_size"].default == 256
+    assert list(inspect.signature(slim.lora.quantize_lora).parameters) == ["model", "bitwidth", "lora_tile_size"]
+    assert list(inspect.signature(Q.attach_input_quantization_hooks).parameters)[:3] == ["model", "num_bits", "input_group_size"]
+    assert list(inspect.signature(slim.eval.eval_ppl_wikitext).parameters)[:4] == ["model", "testenc", "bs", "device"]
+    assert slim.prune.prune_and_quantize is __import__("slim_amd.prune", fromlist=["x"]).prune_and_quantize
+
+
+def test_lora_rank_rule():
+    from slim_amd.lora import lora_rank
+    for shape, ratio, tile in [((4096, 4096), 0.1, 256), ((11008, 4096), 0.1, 256), ((768, 768), 0.1, 256),
+                               ((1024, 8192), 0.1, 256), ((256, 512), 0.1, None), ((512, 512), 0.25, 128)]:
+        assert lora_rank(shape, ratio, tile) == O.lora_rank_for(shape, ratio, tile)
+    assert lora_rank((4096, 4096), 0.1, 256) == 512 and lora_rank((768, 768), 0.1, 256) == 256
+
+
+def test_synthetic_loaders_shapes():
+    from slim_amd.data import get_loaders
+    train, test = get_loaders("synthetic", nsamples=5, seed=0, seqlen=16, vocab_size=100)
+    assert len(train) == 5 and train[0][0].shape == (1, 16) and train[0][1] is None
+    assert test.input_ids.shape == (1, 64 * 16) and int(test.input_ids.max()) < 100
+    with pytest.raises(NotImplementedError, match="network"):
+        get_loaders("c4", 1, 0, 16, None)
+
+
+def test_eval_ppl_harness_semantics():
+    """bf16 loss per batch, exp(sum nll / tokens): same numbers as a direct restatement on CPU."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from slim_amd.eval import eval_ppl_wikitext
+    torch.manual_seed(0)
+    m = LlamaForCausalLM(LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                     num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=16))
+    m = m.to(torch.bfloat16).eval()
+    ids = torch.randint(0, 64, (1, 16 * 5 + 3), generator=torch.Generator().manual_seed(1))
+
+    class Enc:
+        input_ids = ids
+    got = eval_ppl_wikitext(m, Enc, bs=2, device="cpu")
+    nll, n = 0.0, 5
+    with torch.no_grad():
+        for i in range(0, n, 2):
+            j = min(i + 2, n)
+            x = ids[:, i * 16:j * 16].reshape(j - i, 16)
+            lg = m(x).logits
+            loss = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, 64), x[:, 1:].reshape(-1))
+            assert loss.dtype == torch.bfloat16
+            nll += float(loss.float() * 16 * (j - i))
+    assert got == pytest.approx(float(torch.exp(torch.tensor(nll / (n * 16)))), rel=1e-6)
+    got32 = eval_ppl_wikitext(m, Enc, bs=2, device="cpu", fp32_loss=True)
+    assert abs(got32 / got - 1) < 0.05
+
+
+def test_wrapper_state_and_cpu_refusal():
+    from slim_amd.layerwrapper import WrappedGPT
+    lin = torch.nn.Linear(16, 8, bias=False).to(torch.bfloat16)
+    w = WrappedGPT(lin, layer_id=3, layer_name="q")
+    assert w.rows == 8 and w.columns == 16 and w.nsamples == 0 and w.scaler_row.shape == (16,)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        w.add_batch(torch.zeros(1, 4, 16, dtype=torch.bfloat16), None)
