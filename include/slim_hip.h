@@ -84,13 +84,14 @@ int slim_hist_abs_bf16(const void* W_bf16, int64_t numel, uint32_t* hist, int ac
 /* find_optimal_quantiztion_cap, slim/quantization/quantization.py:34-62 with compute_average_error
  * :6-20, from the pattern histogram: rebuilds the reference's density histogram over
  * [min|w|, max|w|] with num_bins bins, runs the coarse (every num_bins/10) and fine scans and
- * returns alpha = val[argmin] (device float), its bin index, and sf = (2^(bits-1)-1) / alpha.
+ * returns alpha = val[argmin] (device float), its bin index, and the scaling factor
+ * sf = reciprocal(alpha) * (2^(bits-1)-1), which is how `max_q / abs_max` evaluates at :194.
  * idx_out, sf_out may be NULL. */
 int64_t slim_quant_search_workspace_bytes(int num_bins);
 int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out, int32_t* idx_out,
                       float* sf_out, void* workspace, int64_t workspace_bytes, void* stream);
 /* abs-max scale (slim_quant = False, quantization.py:190-194): alpha = max|w| (bf16 value),
- * sf = bf16(maxq / alpha) widened to fp32. */
+ * sf = bf16(bf16(1 / alpha) * maxq) widened to fp32. */
 int slim_absmax_scale(const uint32_t* hist, int num_bits, float* alpha_out, float* sf_out, void* stream);
 
 /* Quantizer.quantize_block, quantization.py:194-200:

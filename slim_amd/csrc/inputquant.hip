@@ -87,7 +87,7 @@ extern "C" int slim_input_fake_quant_fp8(const void* x, int64_t numel, void* out
 
 // Integer group branch (Quantizer.quantize_input / dequantize_input, symmetric): one wave per group.
 //   range = max|x| over the group (bf16); range < eps * maxq -> 1
-//   scale = bf16(maxq / range); q = clamp(round(bf16(x * scale)), -maxq-1, maxq); out = bf16(q / scale)
+//   scale = bf16(bf16(1 / range) * maxq); q = clamp(round(bf16(x * scale)), -maxq-1, maxq); out = bf16(q / scale)
 __global__ __launch_bounds__(256) void input_int_kernel(const bf16_t* __restrict__ x, int64_t n_groups, int group,
                                                         float maxq, float thr, bf16_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void input_int_kernel(const bf16_t* __restrict
     }
     float range = bf16_to_f32((bf16_t)m);
     if (range < thr) range = 1.f;
-    const float scale = round_bf16(maxq / range);
+    const float scale = round_bf16(round_bf16(1.0f / range) * maxq);   // `max_q / range` = reciprocal(range) * max_q in bf16
     bf16_t* o = out + gidx * group;
     for (int i = lane; i < group; i += 64) {
         const float prod = round_bf16(bf16_to_f32(p[i]) * scale);

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(1024) void search_argmin_kernel(const float* ws_bas
         const float alpha = ws.val[besti];
         alpha_out[0] = alpha;
         if (idx_out) idx_out[0] = besti;
-        if (sf_out) sf_out[0] = (float)((1 << (num_bits - 1)) - 1) / alpha;
+        // `max_q / abs_max` with a tensor divisor evaluates as reciprocal(abs_max) * max_q (two roundings)
+        if (sf_out) sf_out[0] = (1.0f / alpha) * (float)((1 << (num_bits - 1)) - 1);
     }
 }
 
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(1024) void absmax_from_hist_kernel(const uint32_t* 
     if (threadIdx.x == 0) {
         const float a = bf16_to_f32((bf16_t)s_hi);
         alpha_out[0] = a;
-        if (sf_out) sf_out[0] = round_bf16((float)((1 << (num_bits - 1)) - 1) / a);
+        // bf16 reciprocal, then bf16 product with max_q
+        if (sf_out) sf_out[0] = round_bf16(round_bf16(1.0f / a) * (float)((1 << (num_bits - 1)) - 1));
     }
 }
 

@@ -181,8 +181,8 @@ def test_scale_search_golden(ops, golden, tag):
     # the reference's own argmin may sit on a neighbouring bin when two fp32 losses tie to rounding
     ref_alpha = 7.0 / ref_sf
     assert abs(float(alpha) - ref_alpha) <= 2.5 * float(val[1] - val[0]) + 1e-6 * ref_alpha
-    if abs(float(alpha) - ref_alpha) <= 1e-6 * ref_alpha:
-        assert float(sf) == pytest.approx(ref_sf, rel=1e-6)
+    if int(idx) == int(torch.argmin((g[tag + "_val"] - ref_alpha).abs())):
+        assert float(sf) == ref_sf      # same bin -> bit-identical scaling factor
 
 
 def test_quantize_golden(ops, golden):
