@@ -56,14 +56,19 @@ def partition(costs, world):
     return partition_by_cost(costs, world)
 
 
-def compress_linear(lin, X, nsamples):
-    """The per-linear body of slim_amd.prune.prune_wanda, on a resident activation tensor."""
-    from slim_amd import ops
+def collect_stats(lin, X):
+    """What the calibration forward's hook does for one linear: 128 per-sample add_batch updates."""
     from slim_amd.layerwrapper import WrappedGPT
-    from slim_amd.lora import add_lora
-    from slim_amd.quantization.quantization import Quantizer
     wrapped = WrappedGPT(lin)
     wrapped.add_batch(X, None, per_sample=True)
+    return wrapped
+
+
+def compress_linear(lin, wrapped):
+    """The per-linear body of slim_amd.prune.prune_wanda after the statistics pass."""
+    from slim_amd import ops
+    from slim_amd.lora import add_lora
+    from slim_amd.quantization.quantization import Quantizer
     wrapped.scaler_row = ops.shift_zeros(wrapped.scaler_row)
     mask = ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), 2, 4)
     quantizer = Quantizer("weight", num_bits=4, slim_quant=True)
@@ -73,7 +78,7 @@ def compress_linear(lin, X, nsamples):
     r = torch.tensor(lin.lora_left.shape[1])
     lin.lora_left.data = lin.lora_left.data * torch.sqrt(r)
     lin.lora_right.data = lin.lora_right.data * torch.sqrt(r)
-    return mask
+    return [lin.weight.data, lin.lora_left.data, lin.lora_right.data, lin.scaling_factor]
 
 
 def cpu_baseline(seconds_budget=30.0):
@@ -105,6 +110,7 @@ def main():
     ap.add_argument("--nsamples", type=int, default=128)
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the linears of a block are spread over")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,10 +144,18 @@ def main():
     W0 = {i: synth_weight(n, k, 100 + i, dev) for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK)}
     block_bytes = sum(2.0 * n * k for _, n, k, _ in LLAMA2_7B_BLOCK)
 
+    from slim_amd import ops
+    from slim_amd.prune import run_on_streams
+
     def step():
-        for i in mine:
+        wrapped = {}
+        for i in mine:                      # statistics pass (in the driver: hooks of the block forward)
             lins[i].weight.data = W0[i]
-            compress_linear(lins[i], acts[LLAMA2_7B_BLOCK[i][3]], args.nsamples)
+            wrapped[i] = collect_stats(lins[i], acts[LLAMA2_7B_BLOCK[i][3]])
+        flags = torch.stack([ops.any_zero_flag(wrapped[i].scaler_row) for i in mine]).cpu()     # one host sync
+        for i, z in zip(mine, flags.tolist()):
+            wrapped[i].has_zero = bool(z)
+        run_on_streams([lambda i=i: compress_linear(lins[i], wrapped[i]) for i in mine], dev, args.streams)
         if world > 1:
             # exchange step: every rank receives the compressed shards of the linears it does not own
             for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK):

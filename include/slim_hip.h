@@ -24,6 +24,7 @@ extern "C" {
 
 #define SLIM_HIP_ABI_VERSION 1
 #define SLIM_FIT_INFO_WORDS 64
+#define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 
 int slim_abi_version(void);
 const char* slim_last_error(void); /* host string, valid until the next failing call on this thread */
@@ -130,8 +131,8 @@ int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, i
  *   (rocSOLVER status words, all zero on success; may be NULL). */
 int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l);
 int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter, uint32_t seed,
-                     const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out, void* workspace,
-                     int64_t workspace_bytes, void* stream);
+                     int flags, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
  * N x K low-rank product itself) is written too when non-NULL. */

@@ -4,9 +4,9 @@
 // Here the leading r singular triplets are found by randomized subspace iteration with
 // oversampling: every product with the N x K matrix is a bf16 MFMA GEMM (gemm.hip, NT form,
 // the tall factors are carried both as X and X^T so no product needs a strided operand), the
-// iterate is re-orthonormalised after every product by Cholesky-QR (l x l Gram by MFMA,
-// rocSOLVER potrf + trtri on the l x l factor, one more GEMM), and the final Rayleigh-Ritz
-// step diagonalises the l x l matrix (Q^T E)(Q^T E)^T with rocSOLVER syevd.
+// iterate is re-orthonormalised after every product by a Newton-Schulz polynomial iteration that
+// is itself only GEMMs (or, selectably, by Cholesky-QR through rocSOLVER potrf + trtri), and the
+// final Rayleigh-Ritz step diagonalises the l x l matrix (Q^T E)(Q^T E)^T with rocSOLVER syevd.
 //
 //   E   [N, K]  error matrix (bf16), Et [K, N] its transpose
 //   l = r + oversampling,  q = number of subspace iterations
@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <map>
+#include <utility>
 
 // ---- rocSOLVER / rocBLAS entry points, resolved at first use ---------------------------------
 // (values of the rocBLAS enums are part of its stable C ABI)
@@ -35,7 +36,7 @@ struct Solver {
     fn_potrf potrf = nullptr;
     fn_trtri trtri = nullptr;
     fn_syevd syevd = nullptr;
-    std::map<int, rb_handle> handles;  // per device
+    std::map<std::pair<int, hipStream_t>, rb_handle> handles;  // per (device, stream): rocSOLVER keeps device workspace in the handle
     std::mutex mu;
 };
 Solver g_solver;
@@ -66,14 +67,15 @@ int solver_handle(hipStream_t st, rb_handle* out) {
     int dev = 0;
     SLIM_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_solver.mu);
-    auto it = g_solver.handles.find(dev);
+    const auto key = std::make_pair(dev, st);
+    auto it = g_solver.handles.find(key);
     if (it == g_solver.handles.end()) {
         rb_handle h = nullptr;
         if (g_solver.create(&h) != 0 || !h) {
             slim_set_error("rocblas_create_handle failed");
             return SLIM_ERR_SOLVER;
         }
-        it = g_solver.handles.emplace(dev, h).first;
+        it = g_solver.handles.emplace(key, h).first;
     }
     if (g_solver.set_stream(it->second, st) != 0) {
         slim_set_error("rocblas_set_stream failed");
@@ -162,17 +164,57 @@ extern "C" int slim_scale_rows_bf16(void* L, const float* s, int64_t K, int64_t 
     return SLIM_OK;
 }
 
+// ---- Newton-Schulz helper kernels ------------------------------------------------------------------
+// scal[0] = 1 / sqrt(||G||_F): after X <- scal * X every singular value of X is <= 1 (and >= l^(-1/4)
+// of the largest), the range in which the polynomial iteration below is stable.
+__global__ __launch_bounds__(1024) void fro_rsqrt_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ scal) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double v = (double)g[i];
+        acc += v * v;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        const double fro = sqrt(t);
+        scal[0] = fro > 0.0 ? (float)(1.0 / sqrt(fro)) : 1.0f;
+    }
+}
+
+// P = c * (a I + b c^2 G + q c^4 G2), bf16 [l, l]; c = scal[0] or 1 when scal == NULL.
+__global__ void ns_poly_kernel(const float* __restrict__ G, const float* __restrict__ G2, const float* __restrict__ scal,
+                               float a, float b, float q, int l, bf16_t* __restrict__ P) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= l) return;
+    const float c = scal ? scal[0] : 1.f;
+    const float c2 = c * c;
+    const int64_t o = (int64_t)i * l + j;
+    float v = b * c2 * G[o] + (q != 0.f ? q * c2 * c2 * G2[o] : 0.f);
+    if (i == j) v += a;
+    P[o] = f32_to_bf16(c * v);
+}
+
 // ---- workspace ----------------------------------------------------------------------------------
 static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 
+struct Pair {
+    bf16_t *X, *Xt;  // [rows, l] and its transpose [l, rows]
+};
 struct FitWs {
-    bf16_t *A0, *A0T, *A1, *A1T;  // row-side iterates  [N, l] / [l, N]  (Y then Q), ping-pong
-    bf16_t *B0, *B0T, *B1, *B1T;  // column-side iterates [K, l] / [l, K] (Z then P), ping-pong
-    float* G;                     // [l, l] Gram matrix / Cholesky factor / eigenvectors
-    bf16_t* T16;                  // [l, l] inv(R)^T, later [r, l] leading eigenvectors
-    float* evals;                 // [l]
-    float* ework;                 // [l]
-    int* info;                    // [SLIM_FIT_INFO_WORDS]
+    Pair A[3];      // row-side iterates (rows = N): Y / Q, rotating
+    Pair B[3];      // column-side iterates (rows = K): Z / P, rotating
+    float* G;       // [l, l] Gram matrix / Cholesky factor / eigenvectors
+    float* G2;      // [l, l] square of the Gram matrix
+    bf16_t* G16;    // [l, l] bf16 copy of G
+    bf16_t* T16;    // [l, l] polynomial / inv(R)^T, later [r, l] leading eigenvectors
+    float* evals;   // [l]
+    float* ework;   // [l]
+    float* scal;    // [4]
+    int* info;      // [SLIM_FIT_INFO_WORDS]
     int64_t total;
 };
 static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
@@ -183,18 +225,21 @@ static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
         o += al256(bytes);
         return p;
     };
-    w.A0 = (bf16_t*)take(N * l * 2);
-    w.A0T = (bf16_t*)take(N * l * 2);
-    w.A1 = (bf16_t*)take(N * l * 2);
-    w.A1T = (bf16_t*)take(N * l * 2);
-    w.B0 = (bf16_t*)take(K * l * 2);
-    w.B0T = (bf16_t*)take(K * l * 2);
-    w.B1 = (bf16_t*)take(K * l * 2);
-    w.B1T = (bf16_t*)take(K * l * 2);
+    for (int i = 0; i < 3; ++i) {
+        w.A[i].X = (bf16_t*)take(N * l * 2);
+        w.A[i].Xt = (bf16_t*)take(N * l * 2);
+    }
+    for (int i = 0; i < 3; ++i) {
+        w.B[i].X = (bf16_t*)take(K * l * 2);
+        w.B[i].Xt = (bf16_t*)take(K * l * 2);
+    }
     w.G = (float*)take(l * l * 4);
+    w.G2 = (float*)take(l * l * 4);
+    w.G16 = (bf16_t*)take(l * l * 2);
     w.T16 = (bf16_t*)take(l * l * 2);
     w.evals = (float*)take(l * 4);
     w.ework = (float*)take(l * 4);
+    w.scal = (float*)take(16);
     w.info = (int*)take(SLIM_FIT_INFO_WORDS * 4);
     w.total = o;
     return w;
@@ -211,12 +256,13 @@ extern "C" int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_
         if (rc__) return rc__; \
     } while (0)
 
-// (Q, Qt) <- orthonormal basis of the column space of X [rows, l] (Xt [l, rows] its transpose):
-// G = X^T X, G = R^T R, Q = X inv(R).
-static int cholesky_qr(rb_handle h, const bf16_t* X, const bf16_t* Xt, bf16_t* Q, bf16_t* Qt, int64_t rows, int l,
-                       FitWs& w, int* info, void* stream) {
+// Cholesky-QR: dst <- orthonormal basis of the column space of src (G = X^T X = R^T R, Q = X inv(R)),
+// rocSOLVER potrf + trtri on the l x l factor.
+static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, FitWs& w, int* info, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    CHK(slim_gemm_nt_bf16(Xt, rows, Xt, rows, l, l, (int)rows, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
+    rb_handle h = nullptr;
+    CHK(solver_handle(st, &h));
+    CHK(slim_gemm_nt_bf16(src.Xt, rows, src.Xt, rows, l, l, (int)rows, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
     ridge_kernel<<<1, 256, 0, st>>>(w.G, l, 1e-6f);
     SLIM_LAUNCH_CHECK();
     int solver_tok = g_slim_prof_on ? slim_prof_begin("solver_potrf_trtri", st, 0.0, (double)l * l * l) : -1;
@@ -232,12 +278,55 @@ static int cholesky_qr(rb_handle h, const bf16_t* X, const bf16_t* Xt, bf16_t* Q
     dim3 grid((unsigned)((l + 255) / 256), (unsigned)l);
     tri_to_bf16_kernel<<<grid, 256, 0, st>>>(w.G, l, w.T16);
     SLIM_LAUNCH_CHECK();
-    return slim_gemm_nt_bf16(X, l, w.T16, l, (int)rows, l, l, 1.f, 0.f, nullptr, 0, Q, l, Qt, rows, stream);
+    return slim_gemm_nt_bf16(src.X, l, w.T16, l, (int)rows, l, l, 1.f, 0.f, nullptr, 0, dst.X, l, dst.Xt, rows, stream);
+}
+
+// Newton-Schulz orthonormalisation on MFMA: X <- X p(X^T X) keeps the column space and drives every
+// singular value towards 1.  `nq` quintic steps (3.4445, -4.7750, 2.0315: fast, settles in [0.68, 1.13]),
+// then `nc` cubic steps (1.5, -0.5: converges to 1 quadratically).  Each step is the l x l Gram matrix
+// (one tall GEMM), its square (one small GEMM), the polynomial (element-wise) and X P (one tall GEMM).
+// bufs[cur] holds the input; returns the index of the buffer holding the result.
+static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, FitWs& w, void* stream, int* out_idx) {
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 pgrid((unsigned)((l + 255) / 256), (unsigned)l);
+    for (int sidx = 0; sidx < nq + nc; ++sidx) {
+        const bool quintic = sidx < nq;
+        const Pair& x = bufs[cur];
+        const int nxt = (cur + 1) % 3;
+        CHK(slim_gemm_nt_bf16(x.Xt, rows, x.Xt, rows, l, l, (int)rows, 1.f, 0.f, w.G, l, w.G16, l, nullptr, 0, stream));
+        if (sidx == 0) {
+            fro_rsqrt_kernel<<<1, 1024, 0, st>>>(w.G, (int64_t)l * l, w.scal);
+            SLIM_LAUNCH_CHECK();
+        }
+        if (quintic)
+            CHK(slim_gemm_nt_bf16(w.G16, l, w.G16, l, l, l, l, 1.f, 0.f, w.G2, l, nullptr, 0, nullptr, 0, stream));
+        ns_poly_kernel<<<pgrid, 256, 0, st>>>(w.G, w.G2, sidx == 0 ? w.scal : nullptr, quintic ? 3.4445f : 1.5f,
+                                              quintic ? -4.7750f : -0.5f, quintic ? 2.0315f : 0.f, l, w.T16);
+        SLIM_LAUNCH_CHECK();
+        // P is symmetric, so it serves as its own transpose in the NT product X P
+        CHK(slim_gemm_nt_bf16(x.X, l, w.T16, l, (int)rows, l, l, 1.f, 0.f, nullptr, 0, bufs[nxt].X, l, bufs[nxt].Xt, rows,
+                              stream));
+        cur = nxt;
+    }
+    *out_idx = cur;
+    return SLIM_OK;
+}
+
+// one orthonormalisation in the selected mode; cur/out index the rotating buffers
+static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, FitWs& w, int* info, void* stream,
+                int* out_idx) {
+    if (flags & SLIM_FIT_CHOLESKY_QR) {
+        const int nxt = (cur + 1) % 3;
+        CHK(cholesky_qr(bufs[cur], bufs[nxt], rows, l, w, info, stream));
+        *out_idx = nxt;
+        return SLIM_OK;
+    }
+    return ns_orth(bufs, cur, rows, l, final_pass ? 5 : 4, final_pass ? 3 : 0, w, stream, out_idx);
 }
 
 extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,
-                                uint32_t seed, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                uint32_t seed, int flags, const float* s, void* U, void* Ut, void* L, float* S,
+                                int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
     SLIM_REQUIRE(E && Et && U && L && workspace, "slim_lowrank_fit: null pointer");
     SLIM_REQUIRE(N > 0 && K > 0 && r > 0 && l >= r && n_iter >= 0, "slim_lowrank_fit: bad sizes");
     SLIM_REQUIRE(l <= N && l <= K, "slim_lowrank_fit: subspace dimension l exceeds min(N, K)");
@@ -252,26 +341,26 @@ extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_
     SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
     const bf16_t* Eb = (const bf16_t*)E;
     const bf16_t* Etb = (const bf16_t*)Et;
-    int ninfo = 0;
+    int ninfo = 0, a = 0, b = 0;
 
-    // P0^T [l, K]: Gaussian test matrix;  Y = E P0
-    CHK(slim_randn_bf16(w.B0T, (int64_t)l * K, seed, stream));
-    CHK(slim_gemm_nt_bf16(w.B0T, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A0T, N, w.A0, l, stream));
-    CHK(cholesky_qr(h, w.A0, w.A0T, w.A1, w.A1T, N, l, w, w.info + ninfo, stream));
+    // P0^T [l, K]: Gaussian test matrix;  Y = E P0;  Q = orth(Y)
+    CHK(slim_randn_bf16(w.B[0].Xt, (int64_t)l * K, seed, stream));
+    CHK(slim_gemm_nt_bf16(w.B[0].Xt, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A[0].Xt, N, w.A[0].X, l, stream));
+    CHK(orth(w.A, 0, N, l, n_iter == 0, flags, w, w.info + ninfo, stream, &a));
     ninfo += 2;
     for (int it = 0; it < n_iter; ++it) {
         // Z = E^T Q ; P = orth(Z)
-        CHK(slim_gemm_nt_bf16(w.A1T, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B0T, K, w.B0, l, stream));
-        CHK(cholesky_qr(h, w.B0, w.B0T, w.B1, w.B1T, K, l, w, w.info + ninfo, stream));
+        CHK(slim_gemm_nt_bf16(w.A[a].Xt, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B[0].Xt, K, w.B[0].X, l, stream));
+        CHK(orth(w.B, 0, K, l, false, flags, w, w.info + ninfo, stream, &b));
         ninfo += 2;
         // Y = E P ; Q = orth(Y)
-        CHK(slim_gemm_nt_bf16(w.B1T, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A0T, N, w.A0, l, stream));
-        CHK(cholesky_qr(h, w.A0, w.A0T, w.A1, w.A1T, N, l, w, w.info + ninfo, stream));
+        CHK(slim_gemm_nt_bf16(w.B[b].Xt, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A[0].Xt, N, w.A[0].X, l, stream));
+        CHK(orth(w.A, 0, N, l, it == n_iter - 1, flags, w, w.info + ninfo, stream, &a));
         ninfo += 2;
     }
     // Rayleigh-Ritz: B = Q^T E (kept as B^T = Z [K, l]); M = B B^T = W diag(S^2) W^T
-    CHK(slim_gemm_nt_bf16(w.A1T, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B0T, K, w.B0, l, stream));
-    CHK(slim_gemm_nt_bf16(w.B0T, K, w.B0T, K, l, l, (int)K, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
+    CHK(slim_gemm_nt_bf16(w.A[a].Xt, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B[0].Xt, K, w.B[0].X, l, stream));
+    CHK(slim_gemm_nt_bf16(w.B[0].Xt, K, w.B[0].Xt, K, l, l, (int)K, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
     int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l) : -1;
     if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, w.evals, w.ework, w.info + ninfo) != 0) {
         slim_set_error("rocsolver_ssyevd failed");
@@ -285,8 +374,8 @@ extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_
         SLIM_LAUNCH_CHECK();
     }
     // L = V_r S_r = B^T W_r  [K, r];  U = Q W_r  [N, r] (+ U^T = lora_right)
-    CHK(slim_gemm_nt_bf16(w.B0, l, w.T16, l, (int)K, r, l, 1.f, 0.f, nullptr, 0, L, r, nullptr, 0, stream));
-    CHK(slim_gemm_nt_bf16(w.A1, l, w.T16, l, (int)N, r, l, 1.f, 0.f, nullptr, 0, U, r, Ut, N, stream));
+    CHK(slim_gemm_nt_bf16(w.B[0].X, l, w.T16, l, (int)K, r, l, 1.f, 0.f, nullptr, 0, L, r, nullptr, 0, stream));
+    CHK(slim_gemm_nt_bf16(w.A[a].X, l, w.T16, l, (int)N, r, l, 1.f, 0.f, nullptr, 0, U, r, Ut, N, stream));
     if (s) CHK(slim_scale_rows_bf16(L, s, K, r, stream));
     if (info_out)
         SLIM_HIP(hipMemcpyAsync(info_out, w.info, SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -73,7 +73,10 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     W = W.contiguous()
     N, K = W.shape
     bits = quantizer.num_bits if quantizer is not None else 4
-    use_slim = bool(slim_lora) and not ops.any_zero(activations.scaler_row)      # lora.py:139
+    has_zero = getattr(activations, "has_zero", None)       # precomputed by the driver (one sync per block)
+    if has_zero is None:
+        has_zero = ops.any_zero(activations.scaler_row)
+    use_slim = bool(slim_lora) and not has_zero                                 # lora.py:139
     s = ops.sqrt(activations.scaler_row) if use_slim else None
 
     # first quantisation (scale search on W) and error matrix  (lora.py:146-156 / :158-169)

@@ -74,11 +74,16 @@ def sqrt(v):
     return out
 
 
-def any_zero(v):
+def any_zero_flag(v):
+    """Device int32 scalar: 1 if any element of v is zero (no host synchronisation)."""
     v = _chk(v, torch.float32, "x")
     flag = torch.empty(1, dtype=torch.int32, device=v.device)
     _lib.call("slim_any_zero_f32", _p(v), v.numel(), _p(flag), _stream())
-    return bool(flag.item())
+    return flag[0]
+
+
+def any_zero(v):
+    return bool(any_zero_flag(v).item())
 
 
 # ---- N:M mask --------------------------------------------------------------------------------
@@ -188,7 +193,7 @@ def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False,
     return C32, C16, Ct
 
 
-def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, want_info=False):
+def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False):
     """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info)."""
     E = _chk(E, BF16, "E")
     Et = _chk(Et, BF16, "Et")
@@ -204,7 +209,7 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, want_info=False):
     S = torch.empty(r, dtype=torch.float32, device=dev)
     info = torch.empty(64, dtype=torch.int32, device=dev)
     ws = _ws(_lib.query("slim_lowrank_fit_workspace_bytes", N, K, l), dev)
-    _lib.call("slim_lowrank_fit", _p(E), _p(Et), N, K, r, l, n_iter, seed, _p(s), _p(U), _p(Ut), _p(L), _p(S),
+    _lib.call("slim_lowrank_fit", _p(E), _p(Et), N, K, r, l, n_iter, seed, int(bool(cholesky_qr)), _p(s), _p(U), _p(Ut), _p(L), _p(S),
               _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 

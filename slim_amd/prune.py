@@ -23,6 +23,43 @@ CALIBRATION_BATCH = 1
 KEEP_ON_DEVICE = False
 # optional callable(i, name, module, wrapped) invoked after each linear is compressed (tests, tracing)
 LAYER_CALLBACK = None
+# HIP streams over which the independent linears of one block are compressed concurrently.  The l x l
+# eigen-solve of one linear is a long chain of tiny kernels; on its own stream it overlaps the GEMM-heavy
+# phases of the other linears.  1 = everything on the current stream.
+COMPRESS_STREAMS = 4
+_side_streams = {}
+
+
+def _streams_for(dev, n):
+    key = (dev.index, n)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _side_streams[key]
+
+
+def run_on_streams(jobs, dev, n_streams=None):
+    """Run independent GPU jobs (callables that only enqueue work and return the tensors they produced)
+    round-robin over side streams that start after the current stream's pending work; the current stream
+    then waits for all of them.  Host order is preserved, only device execution overlaps."""
+    n = COMPRESS_STREAMS if n_streams is None else n_streams
+    main = torch.cuda.current_stream(dev)
+    if n <= 1 or len(jobs) <= 1:
+        for job in jobs:
+            job()
+        return
+    streams = _streams_for(dev, min(n, len(jobs)))
+    ev = torch.cuda.Event()
+    ev.record(main)
+    for idx, job in enumerate(jobs):
+        st = streams[idx % len(streams)]
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            produced = job() or ()
+            for t in produced:          # these outlive the side stream's scope and are used on `main`
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(main)
+    for st in streams:
+        main.wait_stream(st)
 
 
 def _device():
@@ -149,7 +186,12 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         for h in handles:
             h.remove()
 
-        for name in subset:
+        # the `any(scaler_row == 0)` guard of add_lora for every linear with a single host synchronisation
+        zero_flags = torch.stack([ops.any_zero_flag(wrapped_layers[name].scaler_row) for name in subset]).cpu()
+        for name, z in zip(subset, zero_flags.tolist()):
+            wrapped_layers[name].has_zero = bool(z)
+
+        def compress(name):
             progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}")
             lin, wrapped = subset[name], wrapped_layers[name]
             if shift_zero_metrics:
@@ -183,6 +225,10 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                 lin.weight.data[W_mask] = 0
             if LAYER_CALLBACK is not None:
                 LAYER_CALLBACK(i, name, lin, wrapped)
+            return [lin.weight.data, getattr(lin, "scaling_factor", None)] + \
+                   [p.data for p in (getattr(lin, "lora_left", None), getattr(lin, "lora_right", None)) if p is not None]
+
+        run_on_streams([lambda name=name: compress(name) for name in subset], dev)
 
         progress_bar.set_description(f"Layer {i} - Evaluating Output")
         _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)

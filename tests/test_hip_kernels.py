@@ -254,9 +254,9 @@ def test_gemm_nt(ops, M, N, Kd):
     torch.testing.assert_close(C2.cpu(), (0.5 * ref + 2.0 * C32.cpu().double()).float(), rtol=1e-5, atol=tol)
 
 
-def _fit_case(ops, E, r, oversample, n_iter):
+def _fit_case(ops, E, r, oversample, n_iter, cholesky_qr=False):
     Eb = E.to(torch.bfloat16)
-    out = ops.lowrank_fit(g2d(Eb), g2d(Eb.t().contiguous()), r, oversample, n_iter, seed=3)
+    out = ops.lowrank_fit(g2d(Eb), g2d(Eb.t().contiguous()), r, oversample, n_iter, seed=3, cholesky_qr=cholesky_qr)
     assert int(out["info"].abs().sum()) == 0, out["info"]
     U, L = out["U"].cpu().float(), out["L"].cpu().float()
     assert torch.equal(out["Ut"].cpu(), out["U"].cpu().t().contiguous())
@@ -268,21 +268,25 @@ def _fit_case(ops, E, r, oversample, n_iter):
     return err, ref_err, out, Ss
 
 
+@pytest.mark.parametrize("cholesky_qr", [False, True])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_lowrank_fit_golden_inputs(ops, golden, tag):
+def test_lowrank_fit_golden_inputs(ops, golden, tag, cholesky_qr):
     g = golden("g7_add_lora")
     W, sr, mask, tile = g[tag + "_W"], g[tag + "_scaler_row"], g[tag + "_mask"].bool(), int(g[tag + "_tile"])
     ref = O.add_lora(W, mask, sr, 0.1, tile=tile)
     E, r = ref["error_mat"], ref["rank"]
-    err, ref_err, out, Ss = _fit_case(ops, E, r, oversample=r // 2, n_iter=6)
+    err, ref_err, out, Ss = _fit_case(ops, E, r, oversample=r // 2, n_iter=6, cholesky_qr=cholesky_qr)
     # north-star tolerance: reconstruction error within 1e-3 (relative) of the reference's SVD factors
     assert err <= ref_err * (1 + 1e-3), (err, ref_err)
     torch.testing.assert_close(out["S"].cpu()[: r // 2], Ss[: r // 2], rtol=2e-2, atol=0)
 
 
-def test_lowrank_fit_rect(ops):
+@pytest.mark.parametrize("outlier", [1.0, 100.0])
+def test_lowrank_fit_rect(ops, outlier):
     W = synth_weight(2048, 1024, 51)
-    sr = O.shift_zeros(synth_scaler(1024, 52))
+    sr = synth_scaler(1024, 52)
+    sr[:3] *= outlier ** 2        # a few channels with very large activations: sigma_1 / sigma_r in the hundreds
+    sr = O.shift_zeros(sr)
     mask = O.prune_nm(O.saliency(W, sr), 2, 4)
     ref = O.add_lora(W, mask, sr, 0.1, tile=128)
     err, ref_err, out, _ = _fit_case(ops, ref["error_mat"], ref["rank"], oversample=64, n_iter=6)
