@@ -69,7 +69,6 @@ def compress_linear(lin, wrapped):
     from slim_amd import ops
     from slim_amd.lora import add_lora
     from slim_amd.quantization.quantization import Quantizer
-    wrapped.scaler_row = ops.shift_zeros(wrapped.scaler_row)
     mask = ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), 2, 4)
     quantizer = Quantizer("weight", num_bits=4, slim_quant=True)
     add_lora(lin, W_mask=mask, rank_ratio=0.1, slim_lora=True, activations=wrapped, quantizer=quantizer,
@@ -145,16 +144,15 @@ def main():
     block_bytes = sum(2.0 * n * k for _, n, k, _ in LLAMA2_7B_BLOCK)
 
     from slim_amd import ops
-    from slim_amd.prune import run_on_streams
+    from slim_amd.prune import run_on_streams, block_stats
 
     def step():
         wrapped = {}
         for i in mine:                      # statistics pass (in the driver: hooks of the block forward)
             lins[i].weight.data = W0[i]
             wrapped[i] = collect_stats(lins[i], acts[LLAMA2_7B_BLOCK[i][3]])
-        flags = torch.stack([ops.any_zero_flag(wrapped[i].scaler_row) for i in mine]).cpu()     # one host sync
-        for i, z in zip(mine, flags.tolist()):
-            wrapped[i].has_zero = bool(z)
+            wrapped[i].scaler_row = ops.shift_zeros(wrapped[i].scaler_row)
+        block_stats([wrapped[i] for i in mine])                                               # one host sync
         run_on_streams([lambda i=i: compress_linear(lins[i], wrapped[i]) for i in mine], dev, args.streams)
         if world > 1:
             # exchange step: every rank receives the compressed shards of the linears it does not own

@@ -123,19 +123,36 @@ int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, i
                       float beta, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16, void* Ct_bf16,
                       int64_t ldct, void* stream);
 
+/* Same product with the reduction split into `splits` slices whose fp32 partial tiles go to
+ * slab [splits, M, N] and are summed in slice order (deterministic).  For small outputs with a long
+ * reduction (the l x l Gram matrices of the fit). */
+int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
+                             float alpha, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16, int splits,
+                             float* slab, void* stream);
+
+/* Orthonormal basis Q [rows, l] (and Q^T) of the column space of X [rows, l] (Xt = X^T), either by
+ * ns_quintic + ns_cubic Newton-Schulz steps on MFMA or (flags & SLIM_FIT_CHOLESKY_QR) by Cholesky-QR.
+ * Building block of slim_lowrank_fit; also used to deflate outlier columns before the fit. */
+int64_t slim_orthonormalize_workspace_bytes(int64_t rows, int64_t l);
+int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t rows, int l, int flags, int ns_quintic,
+                             int ns_cubic, void* Q, void* Qt, int32_t* info_out, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* Replaces torch.svd + truncation, slim/lora.py:172-185 (+ the bf16 division by sqrt(scaler_row)
  * of :193-195 when s != NULL).  Randomized subspace iteration: l = r + oversampling columns,
  * n_iter power iterations.
  *   E [N, K], Et [K, N] bf16;  outputs U [N, r], Ut [r, N] (= lora_right, may be NULL),
  *   L [K, r] (= lora_left), S fp32 [r] (may be NULL), info_out int32 [SLIM_FIT_INFO_WORDS]
- *   (rocSOLVER status words, all zero on success; may be NULL). */
+ *   (rocSOLVER status words, all zero on success; may be NULL).
+ *   flags: SLIM_FIT_CHOLESKY_QR; ns_steps: quintic Newton-Schulz steps per orthonormalisation (each
+ *   lifts a singular value by up to 3.44x, so ns_steps >= log(condition number) / log(3.44); 0 = 4). */
 int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l);
 int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter, uint32_t seed,
-                     int flags, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,
+                     int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
- * N x K low-rank product itself) is written too when non-NULL. */
+ * N x K low-rank product itself) is written too when non-NULL; mask may be NULL (nothing zeroed). */
 int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W_bf16,
                           const uint8_t* mask, void* Wn_bf16, void* LR_bf16, void* stream);
 /* Same subtraction from a materialised LR, optionally accumulating the |bf16| histogram of Wn. */

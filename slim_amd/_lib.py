@@ -37,8 +37,11 @@ PROTOTYPES = {
     "slim_error_matrix": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
     "slim_transpose_bf16": (i32, [vp, i64, i64, vp, vp]),
     "slim_gemm_nt_bf16": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, f32, vp, i64, vp, i64, vp, i64, vp]),
+    "slim_orthonormalize_workspace_bytes": (i64, [i64, i64]),
+    "slim_orthonormalize_bf16": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_fit_workspace_bytes": (i64, [i64, i64, i64]),
-    "slim_lowrank_fit": (i32, [vp, vp, i64, i64, i32, i32, i32, u32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "slim_gemm_nt_bf16_splitk": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, vp, i64, vp, i64, i32, vp, vp]),
+    "slim_lowrank_fit": (i32, [vp, vp, i64, i64, i32, i32, i32, u32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_residual": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "slim_residual_weight": (i32, [vp, vp, vp, i64, vp, vp, vp]),
     "slim_randn_bf16": (i32, [vp, i64, u32, vp]),

@@ -35,6 +35,10 @@ struct GemmArgs {
     const uint8_t* mask;
     bf16_t* Wn;
     int64_t ldw;
+    // split-K: gridDim.y slices of the reduction; slice z writes its fp32 partial tile to slab[z][M][N]
+    // (no other output), summed afterwards in slice order by splitk_reduce_kernel
+    int splits, ksteps_per_split;
+    float* slab;
 };
 
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
@@ -91,17 +95,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u16x8 ra[4], rb[4];
-    const int nk = (g.Kd + BK - 1) / BK;
-    load_tile(g.A, g.lda, g.M, g.Kd, row0, 0, ra);
-    load_tile(g.B, g.ldb, g.N, g.Kd, col0, 0, rb);
+    const int nk_total = (g.Kd + BK - 1) / BK;
+    const int kt0 = g.splits > 1 ? (int)blockIdx.y * g.ksteps_per_split : 0;
+    const int nk = g.splits > 1 ? min(g.ksteps_per_split, nk_total - kt0) : nk_total;
+    load_tile(g.A, g.lda, g.M, g.Kd, row0, kt0 * BK, ra);
+    load_tile(g.B, g.ldb, g.N, g.Kd, col0, kt0 * BK, rb);
     store_tile(As(0), ra);
     store_tile(Bs(0), rb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile(g.A, g.lda, g.M, g.Kd, row0, (kt + 1) * BK, ra);
-            load_tile(g.B, g.ldb, g.N, g.Kd, col0, (kt + 1) * BK, rb);
+            load_tile(g.A, g.lda, g.M, g.Kd, row0, (kt0 + kt + 1) * BK, ra);
+            load_tile(g.B, g.ldb, g.N, g.Kd, col0, (kt0 + kt + 1) * BK, rb);
         }
         const bf16_t* a_base = As(cur) + (wr * 64 + fr) * LDS_STRIDE + fq * 8;
         const bf16_t* b_base = Bs(cur) + (wc * 64 + fr) * LDS_STRIDE + fq * 8;
@@ -133,6 +139,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
             const int col = col0 + wc * 64 + j * 16 + fr;
             const int rbase = row0 + wr * 64 + i * 16 + fq * 4;
             if (col >= g.N) continue;
+            if (g.splits > 1) {
+                float* sl = g.slab + (int64_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rbase + r < g.M) sl[(int64_t)(rbase + r) * g.N + col] = acc[i][j][r];
+                continue;
+            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
                 if (g.Wn) {
                     const int64_t o = (int64_t)row * g.ldw + col;
                     const float lr = round_bf16(v[r]);
-                    g.Wn[o] = g.mask[o] ? (bf16_t)0 : f32_to_bf16(bf16_to_f32(g.W[o]) - lr);
+                    g.Wn[o] = (g.mask && g.mask[o]) ? (bf16_t)0 : f32_to_bf16(bf16_to_f32(g.W[o]) - lr);
                 }
             }
             if (g.Ct16) {
@@ -166,6 +179,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+// C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n, int N, float alpha, float beta,
+                                     float* __restrict__ C32, int64_t ldc32, bf16_t* __restrict__ C16, int64_t ldc16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int z = 0; z < splits; ++z) acc += slab[(int64_t)z * n + i];
+    const int64_t row = i / N, col = i - row * N;
+    float v = acc * alpha;
+    if (C32) {
+        if (beta != 0.f) v += beta * C32[row * ldc32 + col];
+        C32[row * ldc32 + col] = v;
+    }
+    if (C16) C16[row * ldc16 + col] = f32_to_bf16(v);
+}
+
 static int gemm_launch(const GemmArgs& g, void* stream) {
     SLIM_REQUIRE(g.A && g.B && g.M > 0 && g.N > 0 && g.Kd > 0, "slim_gemm_nt_bf16: bad arguments");
     SLIM_REQUIRE(g.Kd % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.lda >= g.Kd && g.ldb >= g.Kd,
@@ -177,13 +206,59 @@ static int gemm_launch(const GemmArgs& g, void* stream) {
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
     const int lds_bytes = 4 * BM * LDS_STRIDE * (int)sizeof(bf16_t);
     SLIM_HIP(slim_allow_dynamic_lds((const void*)gemm_nt_kernel, lds_bytes));
-    SLIM_PROF(g.Wn ? "gemm_nt_residual" : "gemm_nt", stream,
+    const int mx = g.M > g.N ? g.M : g.N, mn = g.M < g.N ? g.M : g.N;
+    const char* scope = g.Wn ? "gemm_nt_residual"
+                        : (mx <= 1536 && g.Kd > 1536) ? "gemm_nt_gram"        // small output, long reduction
+                        : (mx <= 1536) ? "gemm_nt_small"                      // l x l x l
+                        : (g.Kd <= 1536) ? "gemm_nt_apply"                    // tall x (l x l)
+                        : (mn <= 1536) ? "gemm_nt_sketch"                     // (l x K) x (N x K)^T products with E
+                        : "gemm_nt_big";
+    SLIM_PROF(scope, stream,
               2.0 * ((double)g.M + g.N) * g.Kd + (double)g.M * g.N * ((g.C32 ? 4.0 : 0.0) + (g.C16 ? 2.0 : 0.0) +
                                                                       (g.Ct16 ? 2.0 : 0.0) + (g.Wn ? 5.0 : 0.0)),
               2.0 * g.M * g.N * g.Kd);
+    if (g.splits > 1) {
+        SLIM_REQUIRE(g.slab && !g.Ct16 && !g.Wn, "slim_gemm_nt_bf16: split-K supports C_f32 / C_bf16 outputs only");
+        GemmArgs gs = g;
+        dim3 grid((unsigned)tiles, (unsigned)g.splits);
+        gemm_nt_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(gs);
+        SLIM_LAUNCH_CHECK();
+        const int64_t n = (int64_t)g.M * g.N;
+        splitk_reduce_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(
+            g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32, g.C16, g.ldc16);
+        SLIM_LAUNCH_CHECK();
+        return SLIM_OK;
+    }
     gemm_nt_kernel<<<(unsigned)tiles, 256, lds_bytes, (hipStream_t)stream>>>(g);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
+}
+
+// Split-K variant for products with a small output and a long reduction (the l x l Gram matrices of
+// the fit: 25 output tiles would leave most of the chip idle).  `slab` holds splits * M * N floats.
+extern "C" int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
+                                        float alpha, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16,
+                                        int splits, float* slab, void* stream) {
+    SLIM_REQUIRE(splits >= 1 && (splits == 1 || slab), "slim_gemm_nt_bf16_splitk: bad split arguments");
+    GemmArgs g{};
+    g.A = (const bf16_t*)A;
+    g.lda = lda;
+    g.B = (const bf16_t*)Bt;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.Kd = Kd;
+    g.alpha = alpha;
+    g.C32 = C_f32;
+    g.ldc32 = ldc32;
+    g.C16 = (bf16_t*)C_bf16;
+    g.ldc16 = ldc16;
+    const int nk = (Kd + BK - 1) / BK;
+    if (splits > nk) splits = nk;
+    g.ksteps_per_split = (nk + splits - 1) / splits;
+    g.splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
+    g.slab = slab;
+    return gemm_launch(g, stream);
 }
 
 extern "C" int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
@@ -213,7 +288,7 @@ extern "C" int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int
 // fused with the subtraction and masking of :200-201, so the N x K low-rank matrix is never stored.
 extern "C" int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W,
                                      const uint8_t* mask, void* Wn, void* LR_bf16, void* stream) {
-    SLIM_REQUIRE(W && mask && Wn, "slim_lowrank_residual: null pointer");
+    SLIM_REQUIRE(W && Wn, "slim_lowrank_residual: null pointer");
     GemmArgs g{};
     g.A = (const bf16_t*)U;
     g.lda = r;

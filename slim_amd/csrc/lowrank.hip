@@ -199,6 +199,7 @@ __global__ void ns_poly_kernel(const float* __restrict__ G, const float* __restr
 }
 
 // ---- workspace ----------------------------------------------------------------------------------
+#define GRAM_MAX_SPLITS 16
 static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 
 struct Pair {
@@ -214,6 +215,7 @@ struct FitWs {
     float* evals;   // [l]
     float* ework;   // [l]
     float* scal;    // [4]
+    float* slab;    // [GRAM_MAX_SPLITS, l, l] split-K partials of the Gram products
     int* info;      // [SLIM_FIT_INFO_WORDS]
     int64_t total;
 };
@@ -240,6 +242,7 @@ static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
     w.evals = (float*)take(l * 4);
     w.ework = (float*)take(l * 4);
     w.scal = (float*)take(16);
+    w.slab = (float*)take((int64_t)GRAM_MAX_SPLITS * l * l * 4);
     w.info = (int*)take(SLIM_FIT_INFO_WORDS * 4);
     w.total = o;
     return w;
@@ -248,6 +251,17 @@ static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
 extern "C" int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l) {
     if (N <= 0 || K <= 0 || l <= 0) return 0;
     return fit_ws(nullptr, N, K, l).total;
+}
+
+// G (fp32) and optionally G16 (bf16) <- Xt Xt^T, reduction over `rows` split so that tiles * splits covers the chip
+static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, void* stream) {
+    const int tiles = ((l + 127) / 128) * ((l + 127) / 128);
+    int splits = (512 + tiles - 1) / tiles;
+    const int nk = (int)((rows + 63) / 64);
+    if (splits > nk / 4) splits = nk / 4;      // at least four K-steps per slice
+    if (splits > GRAM_MAX_SPLITS) splits = GRAM_MAX_SPLITS;
+    if (splits < 1) splits = 1;
+    return slim_gemm_nt_bf16_splitk(Xt, rows, Xt, rows, l, l, (int)rows, 1.f, w.G, l, G16, l, splits, w.slab, stream);
 }
 
 #define CHK(x)                 \
@@ -262,7 +276,7 @@ static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, Fi
     hipStream_t st = (hipStream_t)stream;
     rb_handle h = nullptr;
     CHK(solver_handle(st, &h));
-    CHK(slim_gemm_nt_bf16(src.Xt, rows, src.Xt, rows, l, l, (int)rows, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
+    CHK(gram(src.Xt, rows, l, w, nullptr, stream));
     ridge_kernel<<<1, 256, 0, st>>>(w.G, l, 1e-6f);
     SLIM_LAUNCH_CHECK();
     int solver_tok = g_slim_prof_on ? slim_prof_begin("solver_potrf_trtri", st, 0.0, (double)l * l * l) : -1;
@@ -293,7 +307,7 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
         const bool quintic = sidx < nq;
         const Pair& x = bufs[cur];
         const int nxt = (cur + 1) % 3;
-        CHK(slim_gemm_nt_bf16(x.Xt, rows, x.Xt, rows, l, l, (int)rows, 1.f, 0.f, w.G, l, w.G16, l, nullptr, 0, stream));
+        CHK(gram(x.Xt, rows, l, w, w.G16, stream));
         if (sidx == 0) {
             fro_rsqrt_kernel<<<1, 1024, 0, st>>>(w.G, (int64_t)l * l, w.scal);
             SLIM_LAUNCH_CHECK();
@@ -313,19 +327,61 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
 }
 
 // one orthonormalisation in the selected mode; cur/out index the rotating buffers
-static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, FitWs& w, int* info, void* stream,
-                int* out_idx) {
+static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, int nq, FitWs& w, int* info,
+                void* stream, int* out_idx) {
     if (flags & SLIM_FIT_CHOLESKY_QR) {
         const int nxt = (cur + 1) % 3;
         CHK(cholesky_qr(bufs[cur], bufs[nxt], rows, l, w, info, stream));
         *out_idx = nxt;
         return SLIM_OK;
     }
-    return ns_orth(bufs, cur, rows, l, final_pass ? 5 : 4, final_pass ? 3 : 0, w, stream, out_idx);
+    if (!final_pass) return ns_orth(bufs, cur, rows, l, nq, 0, w, stream, out_idx);
+    // last basis before the Rayleigh-Ritz step: it must be orthonormal in every direction, including ones the
+    // polynomial iteration has not lifted yet (a numerically rank-deficient iterate), so finish with an exact
+    // Cholesky-QR on the Newton-Schulz-conditioned matrix
+    int mid = cur;
+    CHK(ns_orth(bufs, cur, rows, l, nq, 0, w, stream, &mid));
+    const int nxt = (mid + 1) % 3;
+    CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info, stream));
+    *out_idx = nxt;
+    return SLIM_OK;
+}
+
+// Orthonormal basis (Q [rows, l], Qt [l, rows]) of the column space of X [rows, l] (Xt its transpose).
+extern "C" int64_t slim_orthonormalize_workspace_bytes(int64_t rows, int64_t l) {
+    if (rows <= 0 || l <= 0) return 0;
+    return fit_ws(nullptr, rows, 8, l).total;
+}
+
+extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t rows, int l, int flags, int ns_quintic,
+                                        int ns_cubic, void* Q, void* Qt, int32_t* info_out, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(X && Xt && Q && Qt && workspace, "slim_orthonormalize_bf16: null pointer");
+    SLIM_REQUIRE(rows > 0 && l > 0 && l <= rows && rows % 8 == 0 && l % 8 == 0,
+                 "slim_orthonormalize_bf16: rows and l must be multiples of 8 with l <= rows");
+    SLIM_REQUIRE(workspace_bytes >= slim_orthonormalize_workspace_bytes(rows, l), "slim_orthonormalize_bf16: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    FitWs w = fit_ws((char*)workspace, rows, 8, l);
+    const size_t bytes = (size_t)rows * l * sizeof(bf16_t);
+    SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    SLIM_HIP(hipMemcpyAsync(w.A[0].X, X, bytes, hipMemcpyDeviceToDevice, st));
+    SLIM_HIP(hipMemcpyAsync(w.A[0].Xt, Xt, bytes, hipMemcpyDeviceToDevice, st));
+    int a = 0;
+    if (flags & SLIM_FIT_CHOLESKY_QR) {
+        CHK(cholesky_qr(w.A[0], w.A[1], rows, l, w, w.info, stream));
+        a = 1;
+    } else {
+        CHK(ns_orth(w.A, 0, rows, l, ns_quintic, ns_cubic, w, stream, &a));
+    }
+    SLIM_HIP(hipMemcpyAsync(Q, w.A[a].X, bytes, hipMemcpyDeviceToDevice, st));
+    SLIM_HIP(hipMemcpyAsync(Qt, w.A[a].Xt, bytes, hipMemcpyDeviceToDevice, st));
+    if (info_out)
+        SLIM_HIP(hipMemcpyAsync(info_out, w.info, SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return SLIM_OK;
 }
 
 extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,
-                                uint32_t seed, int flags, const float* s, void* U, void* Ut, void* L, float* S,
+                                uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S,
                                 int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
     SLIM_REQUIRE(E && Et && U && L && workspace, "slim_lowrank_fit: null pointer");
     SLIM_REQUIRE(N > 0 && K > 0 && r > 0 && l >= r && n_iter >= 0, "slim_lowrank_fit: bad sizes");
@@ -342,25 +398,29 @@ extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_
     const bf16_t* Eb = (const bf16_t*)E;
     const bf16_t* Etb = (const bf16_t*)Et;
     int ninfo = 0, a = 0, b = 0;
+    const int nq = ns_steps > 0 ? (ns_steps > 16 ? 16 : ns_steps) : 4;
+    // when the subspace is the whole space the basis must be orthonormal to working precision in every
+    // direction, however weak: take the exact factorisation
+    if (l == N || l == K) flags |= SLIM_FIT_CHOLESKY_QR;
 
     // P0^T [l, K]: Gaussian test matrix;  Y = E P0;  Q = orth(Y)
     CHK(slim_randn_bf16(w.B[0].Xt, (int64_t)l * K, seed, stream));
     CHK(slim_gemm_nt_bf16(w.B[0].Xt, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A[0].Xt, N, w.A[0].X, l, stream));
-    CHK(orth(w.A, 0, N, l, n_iter == 0, flags, w, w.info + ninfo, stream, &a));
+    CHK(orth(w.A, 0, N, l, n_iter == 0, flags, nq, w, w.info + ninfo, stream, &a));
     ninfo += 2;
     for (int it = 0; it < n_iter; ++it) {
         // Z = E^T Q ; P = orth(Z)
         CHK(slim_gemm_nt_bf16(w.A[a].Xt, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B[0].Xt, K, w.B[0].X, l, stream));
-        CHK(orth(w.B, 0, K, l, false, flags, w, w.info + ninfo, stream, &b));
+        CHK(orth(w.B, 0, K, l, false, flags, nq, w, w.info + ninfo, stream, &b));
         ninfo += 2;
         // Y = E P ; Q = orth(Y)
         CHK(slim_gemm_nt_bf16(w.B[b].Xt, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A[0].Xt, N, w.A[0].X, l, stream));
-        CHK(orth(w.A, 0, N, l, it == n_iter - 1, flags, w, w.info + ninfo, stream, &a));
+        CHK(orth(w.A, 0, N, l, it == n_iter - 1, flags, nq, w, w.info + ninfo, stream, &a));
         ninfo += 2;
     }
     // Rayleigh-Ritz: B = Q^T E (kept as B^T = Z [K, l]); M = B B^T = W diag(S^2) W^T
     CHK(slim_gemm_nt_bf16(w.A[a].Xt, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B[0].Xt, K, w.B[0].X, l, stream));
-    CHK(slim_gemm_nt_bf16(w.B[0].Xt, K, w.B[0].Xt, K, l, l, (int)K, 1.f, 0.f, w.G, l, nullptr, 0, nullptr, 0, stream));
+    CHK(gram(w.B[0].Xt, K, l, w, nullptr, stream));
     int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l) : -1;
     if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, w.evals, w.ework, w.info + ninfo) != 0) {
         slim_set_error("rocsolver_ssyevd failed");

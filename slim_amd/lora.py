@@ -1,5 +1,7 @@
 """Saliency-weighted low-rank adapters (mirror of reference slim/lora.py: add_lora :105-213,
 quantize_lora :56-101), with the full SVD replaced by a randomized rank-r fit on MFMA."""
+import os
+
 import torch
 import tqdm.auto as tqdm
 
@@ -14,6 +16,78 @@ FIT_OVERSAMPLE_DIV = 4
 FIT_MIN_OVERSAMPLE = 64
 FIT_ITERS = 6
 FIT_SEED = 0
+# orthonormalise the iterates by Cholesky-QR through rocSOLVER instead of Newton-Schulz on MFMA
+FIT_CHOLESKY_QR = os.environ.get("SLIM_FIT_CHOLESKY_QR", "0") == "1"
+
+
+def ns_steps_for(spread):
+    """Quintic Newton-Schulz steps per orthonormalisation from the spread max(s) / median(s) of the saliency
+    scales: the error matrix is (benign matrix) x diag(s), so its conditioning inside the leading subspace is
+    bounded by about 8 x spread; each step lifts a singular value by up to 3.44x."""
+    import math
+    kappa = 8.0 * max(float(spread), 1.0)
+    return int(min(12, max(4, math.ceil(math.log(kappa) / math.log(3.44)))))
+
+
+# Columns of the error matrix whose saliency scale exceeds OUTLIER_RATIO x the median are split off and
+# represented exactly before the randomized fit (at most MAX_OUTLIER_COLS of them).  Below that ratio the
+# Newton-Schulz step count (ns_steps_for) absorbs the spread.
+OUTLIER_RATIO = 64.0
+MAX_OUTLIER_COLS = 64
+
+
+def fit_error_matrix(E, Et, rank, s, outlier_cols=None, spread=1.0):
+    """Rank-`rank` factors (U [N, r], Ut [r, N], L [K, r]) of the error matrix E [N, K] (Et its transpose).
+
+    E = (benign matrix) x diag(s).  A few channels with very large activations make a few columns of E
+    orders of magnitude larger than the rest; bf16 iterates cannot carry both scales, so those columns
+    (indices `outlier_cols`, a multiple of 8 of them) are deflated: with Q_O an orthonormal basis of
+    their span, E = Q_O (Q_O^T E) + E', the first term is kept exactly (rank t) and the randomized fit runs on
+    the well-conditioned remainder E' with rank r - t.  L is returned already divided by bf16(s)."""
+    N, K = E.shape
+    over = max(FIT_MIN_OVERSAMPLE, rank // FIT_OVERSAMPLE_DIV)
+    t = 0 if outlier_cols is None else int(outlier_cols.numel())
+    if t == 0 or rank - t < 8:
+        fit = ops.lowrank_fit(E, Et, rank, over, FIT_ITERS, seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
+                              ns_steps=ns_steps_for(spread))
+        return fit["U"], fit["Ut"], fit["L"], fit["info"]
+    # orthonormal basis of the outlier columns (each normalised first: their norms differ by orders of magnitude)
+    EO = torch.index_select(E, 1, outlier_cols).float()
+    EO = (EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)).to(torch.bfloat16).contiguous()
+    # the normalised columns are close to orthogonal already (random directions in N dimensions): two
+    # quintic and three cubic Newton-Schulz steps bring them to an orthonormal basis of the same span
+    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
+    # C = Q_O^T E  [t, K] and its transpose; E' = E - Q_O C.  The outlier columns of E' are not zeroed: they
+    # hold what bf16 rounding of Q_O and C left of those columns, which the fit below can still pick up.
+    _, C, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
+    E2 = ops.lowrank_residual(UO, Ct, E, None)
+    del C
+    fit = ops.lowrank_fit(E2, ops.transpose(E2), rank - t, over, FIT_ITERS, seed=FIT_SEED, s=s,
+                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=ns_steps_for(spread))
+    LO = ops.scale_rows(Ct, s) if s is not None else Ct
+    U = torch.cat([UO, fit["U"]], 1).contiguous()
+    L = torch.cat([LO, fit["L"]], 1).contiguous()
+    Ut = torch.cat([UOt, fit["Ut"]], 0).contiguous()
+    info = torch.cat([info_o, fit["info"]])
+    return U, Ut, L, info
+
+
+def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, ratio=OUTLIER_RATIO, rank=None):
+    """(indices of the outlier columns padded to a multiple of 8, spread of the remaining scales).  One host
+    synchronisation; the driver precomputes the same quantities for a whole block at once."""
+    s = torch.sqrt(scaler_row)
+    top = torch.topk(s, min(max_cols + 1, s.numel()))
+    host = torch.cat([top.values, s.median().reshape(1)]).cpu()
+    return _outliers_from_host(host[:-1].tolist(), float(host[-1]), top.indices, ratio)
+
+
+def _outliers_from_host(top_vals, median, top_idx, ratio=OUTLIER_RATIO):
+    median = max(median, 1e-30)
+    t = sum(1 for v in top_vals[:-1] if v > ratio * median)
+    t = min(-(-t // 8) * 8, len(top_vals) - 1) if t else 0
+    t -= t % 8
+    rest = top_vals[t] / median if t < len(top_vals) else 1.0
+    return (top_idx[:t].contiguous() if t else None), max(rest, 1.0)
 
 
 def lora_rank(shape, rank_ratio, lora_tile_size=None):
@@ -88,10 +162,14 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
 
     rank = lora_rank((N, K), rank_ratio, lora_tile_size)
     rank = min(rank, min(N, K))      # S[:rank] of a min(N, K)-long spectrum (lora.py:184)
-    over = max(FIT_MIN_OVERSAMPLE, rank // FIT_OVERSAMPLE_DIV)
-    fit = ops.lowrank_fit(E, Et, rank, over, FIT_ITERS, seed=FIT_SEED, s=s)
+    if use_slim:
+        cols, spread = getattr(activations, "outlier_cols", "unset"), getattr(activations, "scale_spread", None)
+        if spread is None or isinstance(cols, str):      # not precomputed by the driver
+            cols, spread = outlier_columns(activations.scaler_row)
+    else:
+        cols, spread = None, 1.0
+    U, lora_right, lora_left, fit_info = fit_error_matrix(E, Et, rank, s, cols, spread)
     del E, Et
-    lora_left, lora_right, U = fit["L"], fit["Ut"], fit["U"]
 
     # residual weight W - R^T L^T, masked (lora.py:199-201), then second quantisation (:202-204)
     new_weight = ops.lowrank_residual(U, lora_left, W, W_mask)
@@ -102,7 +180,7 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     module.lora_left = torch.nn.Parameter(lora_left).to(torch.bfloat16).contiguous()
     module.lora_right = torch.nn.Parameter(lora_right).to(torch.bfloat16).contiguous()
     module.weight.data = new_weight.to(torch.bfloat16).contiguous()
-    module.lora_fit_info = fit["info"]
+    module.lora_fit_info = fit_info
 
 
 def _weight_scale(W, quantizer):

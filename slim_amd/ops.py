@@ -193,7 +193,34 @@ def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False,
     return C32, C16, Ct
 
 
-def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False):
+def gemm_nt_splitk(A, Bt, splits, alpha=1.0):
+    """fp32 and bf16 C = alpha * A @ Bt.T with the reduction split into `splits` deterministic slices."""
+    A = _chk(A, BF16, "A")
+    Bt = _chk(Bt, BF16, "Bt")
+    M, Kd = A.shape
+    N = Bt.shape[0]
+    C32 = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    C16 = torch.empty(M, N, dtype=BF16, device=A.device)
+    slab = torch.empty(max(splits, 1) * M * N, dtype=torch.float32, device=A.device)
+    _lib.call("slim_gemm_nt_bf16_splitk", _p(A), Kd, _p(Bt), Kd, M, N, Kd, float(alpha), _p(C32), N, _p(C16), N,
+              splits, _p(slab), _stream())
+    return C32, C16
+
+
+def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
+    """(Q [rows, l], Qt [l, rows], info): orthonormal basis of the column space of X [rows, l]."""
+    X = _chk(X, BF16, "X")
+    Xt = transpose(X) if Xt is None else _chk(Xt, BF16, "Xt")
+    rows, l = X.shape
+    Q, Qt = torch.empty_like(X), torch.empty_like(Xt)
+    info = torch.empty(64, dtype=torch.int32, device=X.device)
+    ws = _ws(_lib.query("slim_orthonormalize_workspace_bytes", rows, l), X.device)
+    _lib.call("slim_orthonormalize_bf16", _p(X), _p(Xt), rows, l, int(bool(cholesky_qr)), ns_quintic, ns_cubic, _p(Q),
+              _p(Qt), _p(info), _p(ws), ws.numel(), _stream())
+    return Q, Qt, info
+
+
+def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0):
     """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info)."""
     E = _chk(E, BF16, "E")
     Et = _chk(Et, BF16, "Et")
@@ -209,16 +236,25 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False)
     S = torch.empty(r, dtype=torch.float32, device=dev)
     info = torch.empty(64, dtype=torch.int32, device=dev)
     ws = _ws(_lib.query("slim_lowrank_fit_workspace_bytes", N, K, l), dev)
-    _lib.call("slim_lowrank_fit", _p(E), _p(Et), N, K, r, l, n_iter, seed, int(bool(cholesky_qr)), _p(s), _p(U), _p(Ut), _p(L), _p(S),
+    _lib.call("slim_lowrank_fit", _p(E), _p(Et), N, K, r, l, n_iter, seed, int(bool(cholesky_qr)), int(ns_steps), _p(s), _p(U), _p(Ut), _p(L), _p(S),
               _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
+
+
+def scale_rows(L, s):
+    """In place: L[k, :] = bf16(L[k, :] / bf16(s[k])) (the division of lora_left by sqrt(scaler_row))."""
+    L = _chk(L, BF16, "L")
+    s = _chk(s, torch.float32, "s")
+    _lib.call("slim_scale_rows_bf16", _p(L), _p(s), L.shape[0], L.shape[1], _stream())
+    return L
 
 
 def lowrank_residual(U, L, W, mask, want_lr=False):
     U = _chk(U, BF16, "U")
     L = _chk(L, BF16, "L")
     W = _chk(W, BF16, "W")
-    mask = _chk(mask, torch.bool, "mask")
+    if mask is not None:
+        mask = _chk(mask, torch.bool, "mask")
     N, K = W.shape
     r = U.shape[1]
     Wn = torch.empty_like(W)

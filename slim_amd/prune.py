@@ -6,6 +6,8 @@ whole run (the reference shuttles every sample CPU<->GPU twice per block), the b
 batched while the statistics keep the reference's one-sample-at-a-time accumulation order, and every
 per-linear step (statistics, mask, scale search, quantisation, low-rank fit) is a HIP kernel.
 """
+import os
+
 import torch
 import torch.nn as nn
 import tqdm.auto as tqdm
@@ -26,7 +28,7 @@ LAYER_CALLBACK = None
 # HIP streams over which the independent linears of one block are compressed concurrently.  The l x l
 # eigen-solve of one linear is a long chain of tiny kernels; on its own stream it overlaps the GEMM-heavy
 # phases of the other linears.  1 = everything on the current stream.
-COMPRESS_STREAMS = 4
+COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "4"))
 _side_streams = {}
 
 
@@ -35,6 +37,26 @@ def _streams_for(dev, n):
     if key not in _side_streams:
         _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
     return _side_streams[key]
+
+
+def block_stats(wrapped_list):
+    """Per-linear scalars the host needs before compressing a block, fetched with ONE synchronisation:
+    has_zero (the any(scaler_row == 0) guard), the indices of outlier channels (saliency scale far above the
+    median; the low-rank fit deflates them) and the spread of the remaining scales (sizes the Newton-Schulz
+    orthonormalisation)."""
+    from .lora import MAX_OUTLIER_COLS, _outliers_from_host
+    rows, idxs = [], []
+    for w in wrapped_list:
+        s = torch.sqrt(w.scaler_row)
+        k = min(MAX_OUTLIER_COLS + 1, s.numel())
+        top = torch.topk(s, k)
+        vals = torch.nn.functional.pad(top.values, (0, MAX_OUTLIER_COLS + 1 - k))
+        rows.append(torch.cat([ops.any_zero_flag(w.scaler_row).float().reshape(1), s.median().reshape(1), vals]))
+        idxs.append((top.indices, k))
+    host = torch.stack(rows).cpu()
+    for w, row, (idx, k) in zip(wrapped_list, host.tolist(), idxs):
+        w.has_zero = bool(row[0])
+        w.outlier_cols, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx)
 
 
 def run_on_streams(jobs, dev, n_streams=None):
@@ -186,16 +208,16 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         for h in handles:
             h.remove()
 
-        # the `any(scaler_row == 0)` guard of add_lora for every linear with a single host synchronisation
-        zero_flags = torch.stack([ops.any_zero_flag(wrapped_layers[name].scaler_row) for name in subset]).cpu()
-        for name, z in zip(subset, zero_flags.tolist()):
-            wrapped_layers[name].has_zero = bool(z)
+        # shift_zeros (prune.py:261-262), then the `any(scaler_row == 0)` guard of add_lora (lora.py:139, which
+        # sees the shifted statistics) for every linear with a single host synchronisation
+        if shift_zero_metrics:
+            for name in subset:
+                wrapped_layers[name].scaler_row = ops.shift_zeros(wrapped_layers[name].scaler_row)
+        block_stats(list(wrapped_layers.values()))
 
         def compress(name):
             progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}")
             lin, wrapped = subset[name], wrapped_layers[name]
-            if shift_zero_metrics:
-                wrapped.scaler_row = ops.shift_zeros(wrapped.scaler_row)
             if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
                 W_mask = lin.weight.mask.to(dev)
                 del lin.weight.mask

@@ -254,6 +254,31 @@ def test_gemm_nt(ops, M, N, Kd):
     torch.testing.assert_close(C2.cpu(), (0.5 * ref + 2.0 * C32.cpu().double()).float(), rtol=1e-5, atol=tol)
 
 
+def test_gemm_splitk_matches_single_pass(ops):
+    gen = torch.Generator().manual_seed(7)
+    A = torch.randn(640, 4096 + 64, generator=gen).to(torch.bfloat16)
+    ref32, ref16, _ = ops.gemm_nt(g2d(A), g2d(A), out_f32=True, out_bf16=True)
+    for splits in (1, 3, 8, 16):
+        c32, c16 = ops.gemm_nt_splitk(g2d(A), g2d(A), splits)
+        torch.testing.assert_close(c32.cpu(), ref32.cpu(), rtol=1e-5, atol=1e-3)
+        again32, _ = ops.gemm_nt_splitk(g2d(A), g2d(A), splits)
+        assert torch.equal(again32, c32)          # slice order is fixed: bitwise reproducible
+    assert (c16.cpu().float() - ref16.cpu().float()).abs().max() <= 0.01 * ref16.float().abs().max()
+
+
+@pytest.mark.parametrize("cholesky_qr", [False, True])
+def test_orthonormalize(ops, cholesky_qr):
+    gen = torch.Generator().manual_seed(11)
+    X = (torch.randn(2048, 64, generator=gen) @ torch.diag(torch.logspace(0, -1.5, 64))).to(torch.bfloat16)
+    Q, Qt, info = ops.orthonormalize(g2d(X), ns_quintic=5, ns_cubic=3, cholesky_qr=cholesky_qr)
+    assert int(info.abs().sum()) == 0 and torch.equal(Qt, Q.t().contiguous())
+    G = Q.float().t() @ Q.float()
+    # orthonormal to the precision the bf16 storage of Q allows
+    assert float((G - torch.eye(64, device=DEV)).abs().max()) < 2e-2
+    Xf = g2d(X).float()
+    assert float((Xf - Q.float() @ (Q.float().t() @ Xf)).norm() / Xf.norm()) < 1e-2     # same column space
+
+
 def _fit_case(ops, E, r, oversample, n_iter, cholesky_qr=False):
     Eb = E.to(torch.bfloat16)
     out = ops.lowrank_fit(g2d(Eb), g2d(Eb.t().contiguous()), r, oversample, n_iter, seed=3, cholesky_qr=cholesky_qr)
@@ -281,7 +306,7 @@ def test_lowrank_fit_golden_inputs(ops, golden, tag, cholesky_qr):
     torch.testing.assert_close(out["S"].cpu()[: r // 2], Ss[: r // 2], rtol=2e-2, atol=0)
 
 
-@pytest.mark.parametrize("outlier", [1.0, 100.0])
+@pytest.mark.parametrize("outlier", [1.0, 100.0, 3000.0])
 def test_lowrank_fit_rect(ops, outlier):
     W = synth_weight(2048, 1024, 51)
     sr = synth_scaler(1024, 52)
@@ -289,7 +314,21 @@ def test_lowrank_fit_rect(ops, outlier):
     sr = O.shift_zeros(sr)
     mask = O.prune_nm(O.saliency(W, sr), 2, 4)
     ref = O.add_lora(W, mask, sr, 0.1, tile=128)
-    err, ref_err, out, _ = _fit_case(ops, ref["error_mat"], ref["rank"], oversample=64, n_iter=6)
+    from slim_amd.lora import fit_error_matrix, outlier_columns
+    # channels with very large activations are deflated before the randomized fit
+    cols, spread = outlier_columns(g2d(sr))
+    assert cols is None or cols.numel() % 8 == 0
+    assert outlier < 100 or cols is not None
+    Eb = g2d(ref["error_mat"].to(torch.bfloat16))
+    U, Ut, L, info = fit_error_matrix(Eb, Eb.t().contiguous(), ref["rank"], None, cols, spread)
+    assert int(info.abs().sum()) == 0 and torch.equal(Ut, U.t().contiguous())
+    out = {"U": U, "L": L}
+    E, r = ref["error_mat"], ref["rank"]
+    Us, Ss, Vs = torch.svd(E)
+    Lr = (torch.diag_embed(Ss[:r]).bfloat16() @ Vs[:, :r].bfloat16().T).t().float()
+    ref_err = torch.norm(E - Us[:, :r].bfloat16().float() @ Lr.t()).item()
+    err = torch.norm(E - out["U"].cpu().float() @ out["L"].cpu().float().t()).item()
+    print("outlier", outlier, "deflated", 0 if cols is None else cols.numel(), "rest spread", spread, "excess", err / ref_err - 1)
     assert err <= ref_err * (1 + 1e-3), (err, ref_err)
 
 
