@@ -1,6 +1,6 @@
-from slim_amd.data import *  # noqa: F401,F403
-from slim_amd import data as _impl
+"""Alias: `slim.data` IS `slim_amd.data` (same module object, so attributes patched on one are seen by both)."""
+import sys
 
+import slim_amd.data as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

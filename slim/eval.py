@@ -1,6 +1,6 @@
-from slim_amd.eval import *  # noqa: F401,F403
-from slim_amd import eval as _impl
+"""Alias: `slim.eval` IS `slim_amd.eval` (same module object, so attributes patched on one are seen by both)."""
+import sys
 
+import slim_amd.eval as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

@@ -1,6 +1,6 @@
-from slim_amd.layerwrapper import *  # noqa: F401,F403
-from slim_amd import layerwrapper as _impl
+"""Alias: `slim.layerwrapper` IS `slim_amd.layerwrapper` (same module object, so attributes patched on one are seen by both)."""
+import sys
 
+import slim_amd.layerwrapper as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

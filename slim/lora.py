@@ -1,6 +1,6 @@
-from slim_amd.lora import *  # noqa: F401,F403
-from slim_amd import lora as _impl
+"""Alias: `slim.lora` IS `slim_amd.lora` (same module object, so attributes patched on one are seen by both)."""
+import sys
 
+import slim_amd.lora as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

@@ -1,6 +1,6 @@
-from slim_amd.prune import *  # noqa: F401,F403
-from slim_amd import prune as _impl
+"""Alias: `slim.prune` IS `slim_amd.prune` (same module object, so attributes patched on one are seen by both)."""
+import sys
 
+import slim_amd.prune as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

@@ -1,6 +1,6 @@
-from slim_amd.quantization.quantization import *  # noqa: F401,F403
-from slim_amd.quantization import quantization as _impl
+"""Alias: `slim.quantization.quantization` IS `slim_amd.quantization.quantization` (same module object)."""
+import sys
 
+import slim_amd.quantization.quantization as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

@@ -1,6 +1,6 @@
-from slim_amd.quantization.utils import *  # noqa: F401,F403
-from slim_amd.quantization import utils as _impl
+"""Alias: `slim.quantization.utils` IS `slim_amd.quantization.utils` (same module object)."""
+import sys
 
+import slim_amd.quantization.utils as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl

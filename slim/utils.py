@@ -1,6 +1,6 @@
-from slim_amd.utils import *  # noqa: F401,F403
-from slim_amd import utils as _impl
+"""Alias: `slim.utils` IS `slim_amd.utils` (same module object, so attributes patched on one are seen by both)."""
+import sys
 
+import slim_amd.utils as _impl
 
-def __getattr__(name):
-    return getattr(_impl, name)
+sys.modules[__name__] = _impl
