@@ -36,45 +36,73 @@ OUTLIER_RATIO = 64.0
 MAX_OUTLIER_COLS = 64
 
 
-def fit_error_matrix(E, Et, rank, s, outlier_cols=None, spread=1.0):
-    """Rank-`rank` factors (U [N, r], Ut [r, N], L [K, r]) of the error matrix E [N, K] (Et its transpose).
+def _round_up8(n):
+    return -(-int(n) // 8) * 8
+
+
+def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
+    """Rank-`rank` factors of the error matrix E [N, K] (Et its transpose): U [N, r8], Ut [r8, N], L [K, r8]
+    with r8 = rank rounded up to a multiple of 8 and the columns >= rank zero (the MFMA products that consume
+    the factors need a reduction length that is a multiple of 8; callers slice [:, :rank] for the adapters).
 
     E = (benign matrix) x diag(s).  A few channels with very large activations make a few columns of E
     orders of magnitude larger than the rest; bf16 iterates cannot carry both scales, so those columns
-    (indices `outlier_cols`, a multiple of 8 of them) are deflated: with Q_O an orthonormal basis of
-    their span, E = Q_O (Q_O^T E) + E', the first term is kept exactly (rank t) and the randomized fit runs on
-    the well-conditioned remainder E' with rank r - t.  L is returned already divided by bf16(s)."""
+    (`outliers` = (index tensor padded to a multiple of 8, number t of real outliers)) are deflated: with
+    Q_O an orthonormal basis of their span, E = Q_O (Q_O^T E) + E', the first term is kept exactly (rank t)
+    and the randomized fit runs on the well-conditioned remainder E' with rank - t columns.  The fit returns
+    its columns by decreasing singular value, so asking it for a multiple of 8 and dropping the tail is the
+    optimal truncation.  L is returned already divided by bf16(s)."""
     N, K = E.shape
-    over = max(FIT_MIN_OVERSAMPLE, rank // FIT_OVERSAMPLE_DIV)
-    t = 0 if outlier_cols is None else int(outlier_cols.numel())
+    r8 = _round_up8(rank)
+    cols, t = outliers if outliers is not None else (None, 0)
     if t == 0 or rank - t < 8:
-        fit = ops.lowrank_fit(E, Et, rank, over, FIT_ITERS, seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
-                              ns_steps=ns_steps_for(spread))
-        return fit["U"], fit["Ut"], fit["L"], fit["info"]
-    # orthonormal basis of the outlier columns (each normalised first: their norms differ by orders of magnitude)
-    EO = torch.index_select(E, 1, outlier_cols).float()
-    EO = (EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)).to(torch.bfloat16).contiguous()
+        over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
+        fit = ops.lowrank_fit(E, Et, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
+                              cholesky_qr=FIT_CHOLESKY_QR, ns_steps=ns_steps_for(spread))
+        U, Ut, L = fit["U"], fit["Ut"], fit["L"]
+        if U.shape[1] != r8:           # rank above the largest multiple of 8 within min(N, K)
+            raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+        if r8 != rank:
+            U[:, rank:] = 0
+            Ut[rank:] = 0
+            L[:, rank:] = 0
+        return U, Ut, L, fit["info"]
+    # orthonormal basis of the outlier columns (each normalised first: their norms differ by orders of
+    # magnitude).  The index list is padded to a multiple of 8; the padding columns are zeroed, and a zero
+    # column stays zero through Newton-Schulz steps, so the basis spans the real outlier columns only.
+    EO = torch.index_select(E, 1, cols).float()
+    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
+    EO[:, t:] = 0
+    EO = EO.to(torch.bfloat16).contiguous()
     # the normalised columns are close to orthogonal already (random directions in N dimensions): two
     # quintic and three cubic Newton-Schulz steps bring them to an orthonormal basis of the same span
     UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
+    UO[:, t:] = 0
+    UOt[t:] = 0
     # C = Q_O^T E  [t, K] and its transpose; E' = E - Q_O C.  The outlier columns of E' are not zeroed: they
     # hold what bf16 rounding of Q_O and C left of those columns, which the fit below can still pick up.
     _, C, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
     E2 = ops.lowrank_residual(UO, Ct, E, None)
     del C
-    fit = ops.lowrank_fit(E2, ops.transpose(E2), rank - t, over, FIT_ITERS, seed=FIT_SEED, s=s,
+    rf = _round_up8(rank - t)
+    over = max(FIT_MIN_OVERSAMPLE, rf // FIT_OVERSAMPLE_DIV)
+    fit = ops.lowrank_fit(E2, ops.transpose(E2), rf, over, FIT_ITERS, seed=FIT_SEED, s=s,
                           cholesky_qr=FIT_CHOLESKY_QR, ns_steps=ns_steps_for(spread))
     LO = ops.scale_rows(Ct, s) if s is not None else Ct
-    U = torch.cat([UO, fit["U"]], 1).contiguous()
-    L = torch.cat([LO, fit["L"]], 1).contiguous()
-    Ut = torch.cat([UOt, fit["Ut"]], 0).contiguous()
+    U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
+    L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
+    U[:, :t] = UO[:, :t]
+    U[:, t:rank] = fit["U"][:, :rank - t]
+    L[:, :t] = LO[:, :t]
+    L[:, t:rank] = fit["L"][:, :rank - t]
     info = torch.cat([info_o, fit["info"]])
-    return U, Ut, L, info
+    return U, ops.transpose(U), L, info
 
 
-def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, ratio=OUTLIER_RATIO, rank=None):
-    """(indices of the outlier columns padded to a multiple of 8, spread of the remaining scales).  One host
-    synchronisation; the driver precomputes the same quantities for a whole block at once."""
+def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, ratio=OUTLIER_RATIO):
+    """((indices of the outlier columns padded to a multiple of 8, number of real outliers) or None, spread of
+    the remaining scales).  One host synchronisation; the driver precomputes the same quantities for a
+    whole block at once (prune.block_stats)."""
     s = torch.sqrt(scaler_row)
     top = torch.topk(s, min(max_cols + 1, s.numel()))
     host = torch.cat([top.values, s.median().reshape(1)]).cpu()
@@ -82,12 +110,13 @@ def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, ratio=OUTLIER_RATIO, 
 
 
 def _outliers_from_host(top_vals, median, top_idx, ratio=OUTLIER_RATIO):
+    """top_vals: the largest scales in decreasing order (one more than may be listed)."""
     median = max(median, 1e-30)
     t = sum(1 for v in top_vals[:-1] if v > ratio * median)
-    t = min(-(-t // 8) * 8, len(top_vals) - 1) if t else 0
-    t -= t % 8
+    t_pad = min(_round_up8(t), (len(top_vals) - 1) // 8 * 8)
+    t = min(t, t_pad)
     rest = top_vals[t] / median if t < len(top_vals) else 1.0
-    return (top_idx[:t].contiguous() if t else None), max(rest, 1.0)
+    return ((top_idx[:t_pad].contiguous(), t) if t else None), max(rest, 1.0)
 
 
 def lora_rank(shape, rank_ratio, lora_tile_size=None):
@@ -163,12 +192,12 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     rank = lora_rank((N, K), rank_ratio, lora_tile_size)
     rank = min(rank, min(N, K))      # S[:rank] of a min(N, K)-long spectrum (lora.py:184)
     if use_slim:
-        cols, spread = getattr(activations, "outlier_cols", "unset"), getattr(activations, "scale_spread", None)
-        if spread is None or isinstance(cols, str):      # not precomputed by the driver
-            cols, spread = outlier_columns(activations.scaler_row)
+        outliers, spread = getattr(activations, "outliers", "unset"), getattr(activations, "scale_spread", None)
+        if spread is None or isinstance(outliers, str):      # not precomputed by the driver
+            outliers, spread = outlier_columns(activations.scaler_row)
     else:
-        cols, spread = None, 1.0
-    U, lora_right, lora_left, fit_info = fit_error_matrix(E, Et, rank, s, cols, spread)
+        outliers, spread = None, 1.0
+    U, lora_right, lora_left, fit_info = fit_error_matrix(E, Et, rank, s, outliers, spread)
     del E, Et
 
     # residual weight W - R^T L^T, masked (lora.py:199-201), then second quantisation (:202-204)
@@ -177,6 +206,8 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
         sf2 = _weight_scale(new_weight, quantizer)
         new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), bits)
         quantizer.scaling_factor = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
+    if lora_left.shape[1] != rank:       # the factors are padded to a multiple of 8 columns
+        lora_left, lora_right = lora_left[:, :rank], lora_right[:rank]
     module.lora_left = torch.nn.Parameter(lora_left).to(torch.bfloat16).contiguous()
     module.lora_right = torch.nn.Parameter(lora_right).to(torch.bfloat16).contiguous()
     module.weight.data = new_weight.to(torch.bfloat16).contiguous()

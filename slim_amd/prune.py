@@ -42,7 +42,7 @@ def _streams_for(dev, n):
 def block_stats(wrapped_list):
     """Per-linear scalars the host needs before compressing a block, fetched with ONE synchronisation:
     has_zero (the any(scaler_row == 0) guard), the indices of outlier channels (saliency scale far above the
-    median; the low-rank fit deflates them) and the spread of the remaining scales (sizes the Newton-Schulz
+    median, which the low-rank fit deflates) and the spread of the remaining scales (sizes the Newton-Schulz
     orthonormalisation)."""
     from .lora import MAX_OUTLIER_COLS, _outliers_from_host
     rows, idxs = [], []
@@ -56,7 +56,7 @@ def block_stats(wrapped_list):
     host = torch.stack(rows).cpu()
     for w, row, (idx, k) in zip(wrapped_list, host.tolist(), idxs):
         w.has_zero = bool(row[0])
-        w.outlier_cols, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx)
+        w.outliers, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx)
 
 
 def run_on_streams(jobs, dev, n_streams=None):

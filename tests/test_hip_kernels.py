@@ -306,8 +306,8 @@ def test_lowrank_fit_golden_inputs(ops, golden, tag, cholesky_qr):
     torch.testing.assert_close(out["S"].cpu()[: r // 2], Ss[: r // 2], rtol=2e-2, atol=0)
 
 
-@pytest.mark.parametrize("outlier", [1.0, 100.0, 3000.0])
-def test_lowrank_fit_rect(ops, outlier):
+@pytest.mark.parametrize("outlier,rank_off", [(1.0, 0), (1.0, 3), (100.0, 0), (3000.0, 0), (3000.0, 5)])
+def test_lowrank_fit_rect(ops, outlier, rank_off):
     W = synth_weight(2048, 1024, 51)
     sr = synth_scaler(1024, 52)
     sr[:3] *= outlier ** 2        # a few channels with very large activations: sigma_1 / sigma_r in the hundreds
@@ -316,19 +316,21 @@ def test_lowrank_fit_rect(ops, outlier):
     ref = O.add_lora(W, mask, sr, 0.1, tile=128)
     from slim_amd.lora import fit_error_matrix, outlier_columns
     # channels with very large activations are deflated before the randomized fit
-    cols, spread = outlier_columns(g2d(sr))
-    assert cols is None or cols.numel() % 8 == 0
-    assert outlier < 100 or cols is not None
+    outl, spread = outlier_columns(g2d(sr))
+    assert outl is None or (outl[0].numel() % 8 == 0 and 0 < outl[1] <= outl[0].numel())
+    assert outlier < 100 or outl is not None
     Eb = g2d(ref["error_mat"].to(torch.bfloat16))
-    U, Ut, L, info = fit_error_matrix(Eb, Eb.t().contiguous(), ref["rank"], None, cols, spread)
+    rank = ref["rank"] - rank_off           # ranks that are not multiples of 8 are padded and truncated
+    U, Ut, L, info = fit_error_matrix(Eb, Eb.t().contiguous(), rank, None, outl, spread)
     assert int(info.abs().sum()) == 0 and torch.equal(Ut, U.t().contiguous())
+    assert U.shape[1] % 8 == 0 and not U[:, rank:].any() and not L[:, rank:].any()
     out = {"U": U, "L": L}
-    E, r = ref["error_mat"], ref["rank"]
+    E, r = ref["error_mat"], rank
     Us, Ss, Vs = torch.svd(E)
     Lr = (torch.diag_embed(Ss[:r]).bfloat16() @ Vs[:, :r].bfloat16().T).t().float()
     ref_err = torch.norm(E - Us[:, :r].bfloat16().float() @ Lr.t()).item()
     err = torch.norm(E - out["U"].cpu().float() @ out["L"].cpu().float().t()).item()
-    print("outlier", outlier, "deflated", 0 if cols is None else cols.numel(), "rest spread", spread, "excess", err / ref_err - 1)
+    print("outlier", outlier, "rank", rank, "deflated", 0 if outl is None else outl[1], "rest spread", spread, "excess", err / ref_err - 1)
     assert err <= ref_err * (1 + 1e-3), (err, ref_err)
 
 
