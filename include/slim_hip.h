@@ -190,6 +190,34 @@ int slim_input_fake_quant_fp8(const void* x_bf16, int64_t numel, void* out_bf16,
 int slim_input_fake_quant_int(const void* x_bf16, int64_t n_groups, int group, int num_bits, float eps,
                               void* out_bf16, void* stream);
 
+/* ---- (6) forward pass of a compressed Linear from packed storage ----------------------------------- */
+
+/* Packed form of the weight the compression leaves in `weight.data` (2:4 sparse, 4-bit, per-tensor
+ * scale; slim/prune.py:281-301 + slim/lora.py:199-204, which the reference keeps as a dense bf16 tensor):
+ * per group of 4 input channels 8 bits of codes and 4 bits of positions, 0.375 byte per dense element,
+ * stored in tiles of 128 rows x 64 channels.  N % 128 == 0, K % 64 == 0. */
+int slim_packed24_bytes(int64_t N, int64_t K, int64_t* vals_bytes, int64_t* meta_bytes);
+/* W bf16 [N, K] with W == bf16(c / sf), c integer in [-8, 7], at most two non-zeros per group of 4.
+ * status (device int32): 0, or bit 0 = a group with more than two non-zeros, bit 1 = a value that is not
+ * a quantisation level of sf.  sf: device fp32 scalar (Quantizer.scaling_factor). */
+int slim_pack24_int4(const void* W_bf16, const float* sf, int64_t N, int64_t K, void* vals, void* meta,
+                     int32_t* status, void* stream);
+/* Exact inverse (a dequantised -0 comes back as +0). */
+int slim_unpack24_int4(const void* vals, const void* meta, const float* sf, int64_t N, int64_t K, void* W_bf16,
+                       void* stream);
+/* nn.Linear forward + add_lora_hook (slim/prune.py:303-321) in two launches from the packed weight:
+ *   t = bf16( bf16(x / a_div) L_eff ),   y = bf16( bf16(x W^T + bias) + bf16( bf16(t / a_div) R_eff ) ).
+ * x bf16 [M, K] (row stride ldx), y bf16 [M, N] (row stride ldy), bias bf16 [N] or NULL.
+ * LeffT bf16 [r128, K] = L_eff^T with rows >= r zero (r128 = r rounded up to 128); ReffT bf16 [N, r8] =
+ * R_eff^T with columns >= r zero (r8 = r rounded up to 8); r = 0: no adapters.
+ * Unquantised adapters (prune.py:317-321): L_eff = bf16(lora_left / sqrt(rank)), same for R_eff, a_div = 1.
+ * Quantised adapters (prune.py:304-315): L_eff / R_eff = the group fake-quantised adapters, a_div = sqrt(rank). */
+int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r);
+int slim_linear24_forward(const void* x_bf16, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta,
+                          const float* sf, int64_t N, const void* bias_bf16, const void* LeffT, const void* ReffT,
+                          int64_t r, float a_div, void* y_bf16, int64_t ldy, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

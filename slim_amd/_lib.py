@@ -52,6 +52,11 @@ PROTOTYPES = {
     "slim_group_fake_quant": (i32, [vp, i64, i64, i32, i32, vp, vp, vp, vp]),
     "slim_input_fake_quant_fp8": (i32, [vp, i64, vp, vp, vp]),
     "slim_input_fake_quant_int": (i32, [vp, i64, i32, i32, f32, vp, vp]),
+    "slim_packed24_bytes": (i32, [i64, i64, vp, vp]),
+    "slim_pack24_int4": (i32, [vp, vp, i64, i64, vp, vp, vp, vp]),
+    "slim_unpack24_int4": (i32, [vp, vp, vp, i64, i64, vp, vp]),
+    "slim_linear24_workspace_bytes": (i64, [i64, i64, i64, i64]),
+    "slim_linear24_forward": (i32, [vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i64, f32, vp, i64, vp, i64, vp]),
 }
 
 ERR_INVALID, ERR_LAUNCH, ERR_UNSUPPORTED, ERR_SOLVER = -1, -2, -3, -4

@@ -167,19 +167,22 @@ extern "C" int slim_scale_rows_bf16(void* L, const float* s, int64_t K, int64_t 
 // ---- Newton-Schulz helper kernels ------------------------------------------------------------------
 // scal[0] = 1 / sqrt(||G||_F): after X <- scal * X every singular value of X is <= 1 (and >= l^(-1/4)
 // of the largest), the range in which the polynomial iteration below is stable.
-__global__ __launch_bounds__(1024) void fro_rsqrt_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ scal) {
-    __shared__ double red[16];
+#define FRO_BLOCKS 64
+__global__ __launch_bounds__(256) void fro_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
+    __shared__ double red[4];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)FRO_BLOCKS * 256) {
         const double v = (double)g[i];
         acc += v * v;
     }
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void fro_rsqrt_kernel(const double* __restrict__ part, float* __restrict__ scal) {
+    const double t = wave_sum_d(part[threadIdx.x]);
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += red[w];
         const double fro = sqrt(t);
         scal[0] = fro > 0.0 ? (float)(1.0 / sqrt(fro)) : 1.0f;
     }
@@ -215,6 +218,7 @@ struct FitWs {
     float* evals;   // [l]
     float* ework;   // [l]
     float* scal;    // [4]
+    double* fro_part;  // [FRO_BLOCKS] partial sums of squares
     float* slab;    // [GRAM_MAX_SPLITS, l, l] split-K partials of the Gram products
     int* info;      // [SLIM_FIT_INFO_WORDS]
     int64_t total;
@@ -242,6 +246,7 @@ static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
     w.evals = (float*)take(l * 4);
     w.ework = (float*)take(l * 4);
     w.scal = (float*)take(16);
+    w.fro_part = (double*)take(FRO_BLOCKS * 8);
     w.slab = (float*)take((int64_t)GRAM_MAX_SPLITS * l * l * 4);
     w.info = (int*)take(SLIM_FIT_INFO_WORDS * 4);
     w.total = o;
@@ -309,7 +314,9 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
         const int nxt = (cur + 1) % 3;
         CHK(gram(x.Xt, rows, l, w, w.G16, stream));
         if (sidx == 0) {
-            fro_rsqrt_kernel<<<1, 1024, 0, st>>>(w.G, (int64_t)l * l, w.scal);
+            fro_partial_kernel<<<FRO_BLOCKS, 256, 0, st>>>(w.G, (int64_t)l * l, w.fro_part);
+            SLIM_LAUNCH_CHECK();
+            fro_rsqrt_kernel<<<1, 64, 0, st>>>(w.fro_part, w.scal);
             SLIM_LAUNCH_CHECK();
         }
         if (quintic)

@@ -335,3 +335,66 @@ def input_fake_quant_int(x, num_bits, group_size, eps=1e-4):
     out = torch.empty_like(x)
     _lib.call("slim_input_fake_quant_int", _p(x), x.numel() // group, group, num_bits, float(eps), _p(out), _stream())
     return out
+
+
+# ---- packed 2:4 int4 weight and the forward pass from it ----------------------------------------------
+
+def packed24_bytes(N, K):
+    import ctypes
+    v, m = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.call("slim_packed24_bytes", N, K, ctypes.addressof(v), ctypes.addressof(m))
+    return v.value, m.value
+
+
+def pack24(W, sf):
+    """(vals uint8, meta uint8) packed form of a 2:4-sparse 4-bit weight W = bf16(c / sf).  Synchronises once to
+    read the status word; raises ValueError when W is not of that form."""
+    W = _chk(W, BF16, "W")
+    sf = _chk(sf, torch.float32, "sf").reshape(-1)[:1]
+    N, K = W.shape
+    vb, mb = packed24_bytes(N, K)
+    vals = torch.empty(vb, dtype=torch.uint8, device=W.device)
+    meta = torch.empty(mb, dtype=torch.uint8, device=W.device)
+    status = torch.empty(1, dtype=torch.int32, device=W.device)
+    _lib.call("slim_pack24_int4", _p(W), _p(sf), N, K, _p(vals), _p(meta), _p(status), _stream())
+    st = int(status.item())
+    if st & 1:
+        raise ValueError("pack24: the weight is not 2:4 sparse (a group of 4 input channels holds more than two non-zeros)")
+    if st & 2:
+        raise ValueError("pack24: the weight holds values that are not 4-bit quantisation levels of the given scaling factor")
+    return vals, meta
+
+
+def unpack24(vals, meta, sf, N, K):
+    vals = _chk(vals, torch.uint8, "vals")
+    meta = _chk(meta, torch.uint8, "meta")
+    sf = _chk(sf, torch.float32, "sf").reshape(-1)[:1]
+    W = torch.empty(N, K, dtype=BF16, device=vals.device)
+    _lib.call("slim_unpack24_int4", _p(vals), _p(meta), _p(sf), N, K, _p(W), _stream())
+    return W
+
+
+def linear24_forward(x, vals, meta, sf, N, bias=None, LeffT=None, ReffT=None, r=0, a_div=1.0, ws=None):
+    """y [M, N] = compressed-Linear forward of x [M, K] (bf16) from the packed weight (+ adapters)."""
+    x = _chk(x, BF16, "x")
+    M, K = x.shape
+    vals = _chk(vals, torch.uint8, "vals")
+    meta = _chk(meta, torch.uint8, "meta")
+    sf = _chk(sf, torch.float32, "sf")
+    if vals.numel() * 4 != N * K or meta.numel() * 8 != N * K:
+        raise ValueError("packed weight does not match N x K")
+    if bias is not None:
+        bias = _chk(bias, BF16, "bias")
+    if r:
+        LeffT = _chk(LeffT, BF16, "LeffT")
+        ReffT = _chk(ReffT, BF16, "ReffT")
+        r8, r128 = -(-r // 8) * 8, -(-r // 128) * 128
+        if tuple(LeffT.shape) != (r128, K) or tuple(ReffT.shape) != (N, r8):
+            raise ValueError(f"adapter operands must be [{r128}, {K}] and [{N}, {r8}]")
+    need = _lib.query("slim_linear24_workspace_bytes", M, N, K, r)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, x.device)
+    y = torch.empty(M, N, dtype=BF16, device=x.device)
+    _lib.call("slim_linear24_forward", _p(x), K, M, K, _p(vals), _p(meta), _p(sf), N, _p(bias), _p(LeffT), _p(ReffT), r,
+              float(a_div), _p(y), N, _p(ws), ws.numel(), _stream())
+    return y

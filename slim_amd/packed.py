@@ -1,0 +1,100 @@
+"""Inference from packed storage: a compressed nn.Linear (2:4 sparse 4-bit weight + low-rank adapters, as
+slim.prune.prune_and_quantize / slim.lora.quantize_lora leave it) is replaced by a module that keeps the
+weight at 0.375 byte per element and runs Linear + adapter hook (reference slim/prune.py:303-321) as two
+fused launches.  The reference itself only emulates this forward with dense bf16 tensors."""
+import math
+
+import torch
+
+from . import ops
+from .utils import get_layers_list, find_layers
+
+
+class PackedLinear(torch.nn.Module):
+    """Drop-in for a compressed nn.Linear (inference only).
+
+    Built from the attributes the compression leaves on the layer: weight.data (dequantised values),
+    scaling_factor, and optionally lora_left [K, r], lora_right [r, N], lora_rank, lora_quantizer.
+    """
+
+    def __init__(self, lin):
+        super().__init__()
+        W = lin.weight.data
+        if not W.is_cuda or W.dtype != torch.bfloat16:
+            raise RuntimeError("PackedLinear needs a bf16 weight on the GPU (slim_amd has no CPU path)")
+        sf = getattr(lin, "scaling_factor", None)
+        if sf is None:
+            raise ValueError("the layer has no scaling_factor: it was not quantised by prune_and_quantize")
+        self.out_features, self.in_features = W.shape
+        self.sf = sf.detach().to(torch.float32).reshape(1).contiguous()
+        self.vals, self.meta = ops.pack24(W.contiguous(), self.sf)
+        self.bias = None if lin.bias is None else lin.bias.data.to(torch.bfloat16).contiguous()
+        self.rank = 0
+        self.a_div = 1.0
+        self.LeffT = self.ReffT = None
+        if hasattr(lin, "lora_left"):
+            r = int(lin.lora_rank)
+            sqrt_r = torch.sqrt(lin.lora_rank)        # on the device the reference computes it on (lora_rank's own)
+            L, R = lin.lora_left.data, lin.lora_right.data
+            q = getattr(lin, "lora_quantizer", None)
+            if q is not None:
+                # QuantizedMatmul re-quantises the stored adapters on every call (quantization.py:313-317)
+                # and the hook divides the activations by sqrt(rank) (prune.py:305-312)
+                if not q.block_quantization:
+                    raise NotImplementedError("PackedLinear supports group-quantised adapters only")
+                L = ops.group_fake_quant(L.contiguous(), q.block_dim, q.num_bits)
+                R = ops.group_fake_quant(R.contiguous(), q.block_dim, q.num_bits)
+                self.a_div = float(sqrt_r)
+            else:
+                # prune.py:317-321 divides the adapters by sqrt(rank) on every call
+                sqrt_r = sqrt_r if sqrt_r.dim() == 0 and not sqrt_r.is_cuda else sqrt_r.to(W.device)
+                L, R = L / sqrt_r, R / sqrt_r
+            r8, r128 = -(-r // 8) * 8, -(-r // 128) * 128
+            self.LeffT = torch.zeros(r128, self.in_features, dtype=torch.bfloat16, device=W.device)
+            self.LeffT[:r] = L.t()
+            self.ReffT = torch.zeros(self.out_features, r8, dtype=torch.bfloat16, device=W.device)
+            self.ReffT[:, :r] = R.t()
+            self.rank = r
+        self._ws = None
+        for hook_id, hook in lin._forward_pre_hooks.items():      # input fake-quantisation hooks carry over
+            self._forward_pre_hooks[hook_id] = hook
+
+    def packed_bytes(self):
+        n = self.vals.numel() + self.meta.numel()
+        if self.rank:
+            n += 2 * (self.LeffT.numel() + self.ReffT.numel())
+        return n
+
+    def dense_weight(self):
+        """The dequantised bf16 weight (what the reference keeps in weight.data)."""
+        return ops.unpack24(self.vals, self.meta, self.sf, self.out_features, self.in_features)
+
+    def forward(self, x):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        y = ops.linear24_forward(x2.contiguous(), self.vals, self.meta, self.sf, self.out_features, self.bias,
+                                 self.LeffT, self.ReffT, self.rank, self.a_div)
+        return y.reshape(*shape[:-1], self.out_features)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, rank={self.rank}, packed 2:4 int4"
+
+
+def pack_model(model):
+    """Replace every compressed Linear of the decoder blocks by a PackedLinear, in place.  Returns
+    (dense bytes, packed bytes) of the replaced layers."""
+    dense = packed = 0
+    for layer in get_layers_list(model):
+        subset = find_layers(layer)
+        for name, lin in subset.items():
+            parent = layer
+            parts = name.split(".")
+            for p in parts[:-1]:
+                parent = getattr(parent, p)
+            pl = PackedLinear(lin)
+            setattr(parent, parts[-1], pl)
+            dense += lin.weight.numel() * 2
+            packed += pl.packed_bytes()
+    return dense, packed

@@ -1,0 +1,157 @@
+"""Packed 2:4 int4 storage and the fused forward pass, against the reference's emulated forward
+(nn.Linear on the dequantised bf16 weight + add_lora_hook, slim/prune.py:303-321) run with torch on the
+same GPU, and against an fp64 evaluation of the same expression."""
+import math
+
+import pytest
+import torch
+
+from oracle import slim_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slim_amd import ops as _ops
+    return _ops
+
+
+def make_weight(N, K, seed, sf=None):
+    """A weight of the form the compression leaves behind: 2:4 sparse, values bf16(c / sf), c in [-8, 7]."""
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.randint(-8, 8, (N, K), generator=g).float()
+    keep = O.prune_nm(torch.rand(N, K, generator=g), 2, 4)        # True = pruned
+    sf = torch.tensor(sf if sf is not None else 37.3, dtype=torch.float32)
+    W = (codes / sf).to(torch.bfloat16)
+    W[keep] = 0
+    return W, sf.reshape(1)
+
+
+def test_pack_unpack_round_trip(ops):
+    for (N, K, seed) in [(128, 64, 1), (256, 512, 2), (1024, 4096, 3)]:
+        W, sf = make_weight(N, K, seed)
+        vals, meta = ops.pack24(W.to(DEV), sf.to(DEV))
+        assert vals.numel() == N * K // 4 and meta.numel() == N * K // 8
+        back = ops.unpack24(vals, meta, sf.to(DEV), N, K).cpu()
+        assert torch.equal(back, W)
+        # bit-identical except that a dequantised -0 is stored as +0
+        assert torch.equal(back.view(torch.int16)[W != 0], W.view(torch.int16)[W != 0])
+
+
+def test_pack_rejects_bad_weights(ops):
+    W, sf = make_weight(128, 64, 4)
+    bad = W.clone()
+    bad[3, 0:4] = torch.tensor([1, 2, 3, 0], dtype=torch.float32).div(sf).to(torch.bfloat16)
+    with pytest.raises(ValueError, match="2:4"):
+        ops.pack24(bad.to(DEV), sf.to(DEV))
+    bad = W.clone()
+    bad[5, 8:12] = torch.tensor([0.01234, 0, 0, 0]).to(torch.bfloat16)
+    with pytest.raises(ValueError, match="levels"):
+        ops.pack24(bad.to(DEV), sf.to(DEV))
+    with pytest.raises(ValueError):
+        ops.pack24(W[:100].contiguous().to(DEV), sf.to(DEV))      # N not a multiple of 128
+
+
+def reference_forward(lin, x):
+    """What the reference runs: nn.Linear on the dequantised weight, then the adapter hook (bf16, torch GEMMs)."""
+    from slim_amd.prune import add_lora_hook
+    y = torch.nn.functional.linear(x, lin.weight.data, lin.bias)
+    if hasattr(lin, "lora_left"):
+        add_lora_hook(lin, (x,), y)
+    return y
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).double()
+
+
+def rounded_fp64_forward(lin, x, ops):
+    """The same expression with the same bf16 rounding points, every matmul accumulated in fp64."""
+    y = bf16r(x.double() @ lin.weight.data.double().t() + (0 if lin.bias is None else lin.bias.data.double()))
+    if hasattr(lin, "lora_left"):
+        sqrt_r = torch.sqrt(lin.lora_rank).to(x.device)
+        q = getattr(lin, "lora_quantizer", None)
+        if q is not None:
+            Lq = ops.group_fake_quant(lin.lora_left.data.contiguous(), q.block_dim, q.num_bits)
+            Rq = ops.group_fake_quant(lin.lora_right.data.contiguous(), q.block_dim, q.num_bits)
+            t = bf16r((x / sqrt_r).double() @ Lq.double())
+            ad = bf16r((t.to(torch.bfloat16) / sqrt_r).double() @ Rq.double())
+        else:
+            t = bf16r(x.double() @ (lin.lora_left.data / sqrt_r).double())
+            ad = bf16r(t @ (lin.lora_right.data / sqrt_r).double())
+        y = bf16r(y + ad)
+    return y
+
+
+def build_layer(N, K, r, seed, bias, quant_block=None):
+    from slim_amd.quantization.quantization import Quantizer
+    W, sf = make_weight(N, K, seed)
+    lin = torch.nn.Linear(K, N, bias=bias).to(torch.bfloat16).to(DEV)
+    lin.weight.data = W.to(DEV)
+    lin.scaling_factor = sf.reshape(1, 1).to(DEV)
+    g = torch.Generator().manual_seed(seed + 100)
+    if bias:
+        lin.bias.data = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    if r:
+        lin.lora_rank = torch.tensor(r)
+        lin.lora_left = torch.nn.Parameter((torch.randn(K, r, generator=g) * 0.05 * math.sqrt(r)).to(torch.bfloat16).to(DEV))
+        lin.lora_right = torch.nn.Parameter((torch.randn(r, N, generator=g) * 0.05 * math.sqrt(r)).to(torch.bfloat16).to(DEV))
+        if quant_block:
+            lin.lora_quantizer = Quantizer("weight", num_bits=4, block_quantization=True, block_dim=quant_block)
+    return lin
+
+
+CASES = [
+    # N, K, r, bias, quantised-adapter block, batch sizes
+    (128, 64, 0, False, None, [1, 16, 130]),
+    (256, 512, 51, True, None, [1, 5, 17, 33, 100, 128, 300]),
+    (256, 512, 128, False, 128, [1, 16, 64, 200]),
+    (1024, 4096, 409, False, None, [1, 16, 48, 1000]),
+    (4096, 1024, 256, True, 128, [2, 128, 513]),
+]
+
+
+@pytest.mark.parametrize("N,K,r,bias,qblock,batches", CASES)
+def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, batches):
+    from slim_amd.packed import PackedLinear
+    lin = build_layer(N, K, r, seed=N + K + r, bias=bias, quant_block=qblock)
+    packed = PackedLinear(lin)
+    assert torch.equal(packed.dense_weight(), lin.weight.data)
+    dense_bytes = N * K * 2
+    assert packed.vals.numel() + packed.meta.numel() == dense_bytes * 3 // 16
+    for M in batches:
+        g = torch.Generator().manual_seed(M)
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+        y = packed(x)
+        assert y.shape == (M, N) and y.dtype == torch.bfloat16
+        ref = reference_forward(lin, x)
+        exact = rounded_fp64_forward(lin, x, ops)
+        # Both sides round the same expression at the same points but accumulate each matmul in a different
+        # order, so individual outputs may differ by a bf16 unit of one of the rounded terms.  Bound: every
+        # output within 2^-6 of the output scale of the torch result, and our distance to the fp64-accumulated
+        # value no larger than the torch path's (x1.25).
+        scale = exact.abs().max().item()
+        diff = (y.double() - ref.double()).abs().max().item()
+        err_ours = (y.double() - exact).norm().item()
+        err_ref = (ref.double() - exact).norm().item()
+        print(f"N={N} K={K} r={r} M={M}: max|ours-torch|={diff:.4g} scale={scale:.4g} "
+              f"err ours={err_ours:.4g} torch={err_ref:.4g} identical={(y == ref).float().mean().item():.4f}")
+        assert diff <= scale * 2.0 ** -6, (M, diff, scale)
+        assert err_ours <= err_ref * 1.25 + 1e-6, (M, err_ours, err_ref)
+
+
+def test_packed_forward_leading_dims_and_hooks(ops):
+    from slim_amd.packed import PackedLinear
+    from slim_amd.quantization.quantization import attach_input_quantization_hooks
+    lin = build_layer(256, 512, 64, seed=9, bias=False)
+    packed = PackedLinear(lin)
+    x = torch.randn(2, 7, 512, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(DEV)
+    y = packed(x)
+    assert y.shape == (2, 7, 256)
+    assert torch.equal(y.reshape(14, 256), packed(x.reshape(14, 512)))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear24_forward(x.reshape(14, 512).cpu(), packed.vals, packed.meta, packed.sf, 256)
