@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--nsamples", type=int, default=128)
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the linears of a block are spread over")
+    ap.add_argument("--streams", type=int, default=7, help="HIP streams the linears of a block are spread over")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -7,6 +7,7 @@ batched while the statistics keep the reference's one-sample-at-a-time accumulat
 per-linear step (statistics, mask, scale search, quantisation, low-rank fit) is a HIP kernel.
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -27,8 +28,9 @@ KEEP_ON_DEVICE = False
 LAYER_CALLBACK = None
 # HIP streams over which the independent linears of one block are compressed concurrently.  The l x l
 # eigen-solve of one linear is a long chain of tiny kernels; on its own stream it overlaps the GEMM-heavy
-# phases of the other linears.  1 = everything on the current stream.
-COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "4"))
+# phases of the other linears.  Each stream is fed by its own host thread (run_on_streams); 7 = one per linear
+# of a LLaMA block.  1 = everything on the current stream.
+COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "7"))
 _side_streams = {}
 
 
@@ -60,9 +62,13 @@ def block_stats(wrapped_list):
 
 
 def run_on_streams(jobs, dev, n_streams=None):
-    """Run independent GPU jobs (callables that only enqueue work and return the tensors they produced)
-    round-robin over side streams that start after the current stream's pending work; the current stream
-    then waits for all of them.  Host order is preserved, only device execution overlaps."""
+    """Run independent GPU jobs (callables that only enqueue work and return the tensors they produced) on side
+    streams that start after the current stream's pending work; the current stream then waits for all of them.
+
+    Each side stream is fed by its own host thread.  One compression job issues thousands of small launches
+    (the eigen-solver alone is a storm of tiny kernels), so a single host thread, not the GPU, is the limit;
+    the library calls release the GIL, which lets the threads enqueue concurrently.  Jobs are assigned
+    round-robin in order, so the stream (and the result) of every job is deterministic."""
     n = COMPRESS_STREAMS if n_streams is None else n_streams
     main = torch.cuda.current_stream(dev)
     if n <= 1 or len(jobs) <= 1:
@@ -72,16 +78,31 @@ def run_on_streams(jobs, dev, n_streams=None):
     streams = _streams_for(dev, min(n, len(jobs)))
     ev = torch.cuda.Event()
     ev.record(main)
-    for idx, job in enumerate(jobs):
-        st = streams[idx % len(streams)]
-        st.wait_event(ev)
-        with torch.cuda.stream(st):
-            produced = job() or ()
-            for t in produced:          # these outlive the side stream's scope and are used on `main`
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(main)
+    errors = []
+
+    def feed(si):
+        try:
+            torch.cuda.set_device(dev)
+            st = streams[si]
+            st.wait_event(ev)
+            with torch.cuda.stream(st), torch.no_grad():
+                for idx in range(si, len(jobs), len(streams)):
+                    produced = jobs[idx]() or ()
+                    for t in produced:          # these outlive the side stream's scope and are used on `main`
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(main)
+        except BaseException as e:              # re-raised on the calling thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=feed, args=(si,), name=f"slim-stream-{si}") for si in range(len(streams))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
     for st in streams:
         main.wait_stream(st)
+    if errors:
+        raise errors[0]
 
 
 def _device():
