@@ -64,22 +64,6 @@ def collect_stats(lin, X):
     return wrapped
 
 
-def compress_linear(lin, wrapped):
-    """The per-linear body of slim_amd.prune.prune_wanda after the statistics pass."""
-    from slim_amd import ops
-    from slim_amd.lora import add_lora
-    from slim_amd.quantization.quantization import Quantizer
-    mask = ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), 2, 4)
-    quantizer = Quantizer("weight", num_bits=4, slim_quant=True)
-    add_lora(lin, W_mask=mask, rank_ratio=0.1, slim_lora=True, activations=wrapped, quantizer=quantizer,
-             lora_tile_size=256, quantize_first=True)
-    lin.scaling_factor = quantizer.scaling_factor
-    r = torch.tensor(lin.lora_left.shape[1])
-    lin.lora_left.data = lin.lora_left.data * torch.sqrt(r)
-    lin.lora_right.data = lin.lora_right.data * torch.sqrt(r)
-    return [lin.weight.data, lin.lora_left.data, lin.lora_right.data, lin.scaling_factor]
-
-
 def cpu_baseline(seconds_budget=30.0):
     """The CPU oracle (torch-CPU restatement of the reference algorithm) on a bounded sample of the same
     workload: one 4096 x 4096 linear of the block with 4 of the 128 calibration samples."""
@@ -144,7 +128,8 @@ def main():
     block_bytes = sum(2.0 * n * k for _, n, k, _ in LLAMA2_7B_BLOCK)
 
     from slim_amd import ops
-    from slim_amd.prune import run_on_streams, block_stats
+    from slim_amd.prune import compress_linears, block_stats
+    from slim_amd.quantization.quantization import Quantizer
 
     def step():
         wrapped = {}
@@ -153,7 +138,12 @@ def main():
             wrapped[i] = collect_stats(lins[i], acts[LLAMA2_7B_BLOCK[i][3]])
             wrapped[i].scaler_row = ops.shift_zeros(wrapped[i].scaler_row)
         block_stats([wrapped[i] for i in mine])                                               # one host sync
-        run_on_streams([lambda i=i: compress_linear(lins[i], wrapped[i]) for i in mine], dev, args.streams)
+        for i in mine:                      # a fresh module state per step (hooks and adapters of the last step)
+            lins[i]._forward_hooks.clear()
+        # the per-linear body of slim_amd.prune.prune_wanda after the statistics pass
+        compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in mine], dev, 2, 4,
+                         quantizer=Quantizer("weight", num_bits=4, slim_quant=True), lora_rank=0.1, slim_lora=True,
+                         quantize_lora=True, lora_tile_size=256, n_streams=args.streams)
         if world > 1:
             # exchange step: every rank receives the compressed shards of the linears it does not own
             for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK):

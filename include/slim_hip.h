@@ -151,6 +151,15 @@ int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r,
                      int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* `batch` fits of identical shape in lockstep (the q/k/v/o or gate/up projections of one decoder block):
+ * E [batch][N, K], Et [batch][K, N], s [batch][K] or NULL, U [batch][N, r], Ut [batch][r, N], L [batch][K, r],
+ * S [batch][r], info_out [batch][SLIM_FIT_INFO_WORDS].  Every launch covers the whole batch, so the launch
+ * count and the dependent chain (in particular the l x l eigen-solve) are those of one fit. */
+int64_t slim_lowrank_fit_batched_workspace_bytes(int batch, int64_t N, int64_t K, int64_t l);
+int slim_lowrank_fit_batched(const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
+                             uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L,
+                             float* S, int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
  * N x K low-rank product itself) is written too when non-NULL; mask may be NULL (nothing zeroed). */
 int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W_bf16,

@@ -11,35 +11,12 @@
 #include "common.hpp"
 #include "../../include/slim_hip.h"
 
+#include "gemm.hpp"
+
 #define BM 128
 #define BN 128
 #define BK 64
 #define LDS_STRIDE (BK + 8)
-
-struct GemmArgs {
-    const bf16_t* A;
-    int64_t lda;
-    const bf16_t* B;
-    int64_t ldb;
-    int M, N, Kd;
-    float alpha, beta;  // C32 = alpha * acc + beta * C32 (beta = 0: C32 is not read)
-    float* C32;
-    int64_t ldc32;
-    bf16_t* C16;
-    int64_t ldc16;
-    bf16_t* Ct16;
-    int64_t ldct;
-    // optional fused epilogue of the adapter subtraction (slim/lora.py:199-201):
-    // Wn = mask ? 0 : bf16(float(W) - float(bf16(acc)))
-    const bf16_t* W;
-    const uint8_t* mask;
-    bf16_t* Wn;
-    int64_t ldw;
-    // split-K: gridDim.y slices of the reduction; slice z writes its fp32 partial tile to slab[z][M][N]
-    // (no other output), summed afterwards in slice order by splitk_reduce_kernel
-    int splits, ksteps_per_split;
-    float* slab;
-};
 
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
                                           u16x8 (&r)[4]) {
@@ -83,6 +60,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tm = wgid / tiles_n, tn = wgid % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
+
+    if (g.batch > 1) {     // strided batch: blockIdx.z selects the problem
+        const int64_t bz = blockIdx.z;
+        g.A += bz * g.sA;
+        g.B += bz * g.sB;
+        if (g.C32) g.C32 += bz * g.sC32;
+        if (g.C16) g.C16 += bz * g.sC16;
+        if (g.Ct16) g.Ct16 += bz * g.sCt;
+        if (g.slab) g.slab += bz * g.sSlab;
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -181,9 +168,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
 // C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n, int N, float alpha, float beta,
-                                     float* __restrict__ C32, int64_t ldc32, bf16_t* __restrict__ C16, int64_t ldc16) {
+                                     float* __restrict__ C32, int64_t ldc32, bf16_t* __restrict__ C16, int64_t ldc16,
+                                     int64_t sSlab, int64_t sC32, int64_t sC16) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int64_t bz = blockIdx.y;          // strided batch
+    slab += bz * sSlab;
+    if (C32) C32 += bz * sC32;
+    if (C16) C16 += bz * sC16;
     float acc = 0.f;
     for (int z = 0; z < splits; ++z) acc += slab[(int64_t)z * n + i];
     const int64_t row = i / N, col = i - row * N;
@@ -195,7 +187,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     if (C16) C16[row * ldc16 + col] = f32_to_bf16(v);
 }
 
-static int gemm_launch(const GemmArgs& g, void* stream) {
+int slim_gemm_launch(const GemmArgs& g, void* stream) {
     SLIM_REQUIRE(g.A && g.B && g.M > 0 && g.N > 0 && g.Kd > 0, "slim_gemm_nt_bf16: bad arguments");
     SLIM_REQUIRE(g.Kd % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.lda >= g.Kd && g.ldb >= g.Kd,
                  "slim_gemm_nt_bf16: Kd, lda, ldb must be multiples of 8 and ld >= Kd");
@@ -204,6 +196,8 @@ static int gemm_launch(const GemmArgs& g, void* stream) {
     SLIM_REQUIRE(!g.Ct16 || ((uintptr_t)g.Ct16 % 8) == 0, "slim_gemm_nt_bf16: Ct must be 8-byte aligned");
     const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
+    const int batch = g.batch > 1 ? g.batch : 1;
+    SLIM_REQUIRE(batch <= 65535 && (batch == 1 || (!g.Wn && g.beta == 0.f)), "slim_gemm_nt_bf16: bad batch arguments");
     const int lds_bytes = 4 * BM * LDS_STRIDE * (int)sizeof(bf16_t);
     SLIM_HIP(slim_allow_dynamic_lds((const void*)gemm_nt_kernel, lds_bytes));
     const int mx = g.M > g.N ? g.M : g.N, mn = g.M < g.N ? g.M : g.N;
@@ -216,20 +210,20 @@ static int gemm_launch(const GemmArgs& g, void* stream) {
     SLIM_PROF(scope, stream,
               2.0 * ((double)g.M + g.N) * g.Kd + (double)g.M * g.N * ((g.C32 ? 4.0 : 0.0) + (g.C16 ? 2.0 : 0.0) +
                                                                       (g.Ct16 ? 2.0 : 0.0) + (g.Wn ? 5.0 : 0.0)),
-              2.0 * g.M * g.N * g.Kd);
+              2.0 * g.M * g.N * g.Kd * batch);
     if (g.splits > 1) {
         SLIM_REQUIRE(g.slab && !g.Ct16 && !g.Wn, "slim_gemm_nt_bf16: split-K supports C_f32 / C_bf16 outputs only");
-        GemmArgs gs = g;
-        dim3 grid((unsigned)tiles, (unsigned)g.splits);
-        gemm_nt_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(gs);
+        dim3 grid((unsigned)tiles, (unsigned)g.splits, (unsigned)batch);
+        gemm_nt_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(g);
         SLIM_LAUNCH_CHECK();
         const int64_t n = (int64_t)g.M * g.N;
-        splitk_reduce_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(
-            g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32, g.C16, g.ldc16);
+        dim3 rgrid((unsigned)ceil_div64(n, 256), (unsigned)batch);
+        splitk_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32,
+                                                                     g.C16, g.ldc16, g.sSlab, g.sC32, g.sC16);
         SLIM_LAUNCH_CHECK();
         return SLIM_OK;
     }
-    gemm_nt_kernel<<<(unsigned)tiles, 256, lds_bytes, (hipStream_t)stream>>>(g);
+    gemm_nt_kernel<<<dim3((unsigned)tiles, 1, (unsigned)batch), 256, lds_bytes, (hipStream_t)stream>>>(g);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
@@ -258,7 +252,7 @@ extern "C" int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* 
     g.ksteps_per_split = (nk + splits - 1) / splits;
     g.splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     g.slab = slab;
-    return gemm_launch(g, stream);
+    return slim_gemm_launch(g, stream);
 }
 
 extern "C" int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
@@ -281,7 +275,7 @@ extern "C" int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int
     g.ldc16 = ldc16;
     g.Ct16 = (bf16_t*)Ct_bf16;
     g.ldct = ldct;
-    return gemm_launch(g, stream);
+    return slim_gemm_launch(g, stream);
 }
 
 // Wn[N,K] = mask ? 0 : bf16(W - bf16(U[N,r] * L[K,r]^T)) : the adapter product of slim/lora.py:199
@@ -304,7 +298,7 @@ extern "C" int slim_lowrank_residual(const void* U, const void* L, int N, int K,
     g.mask = mask;
     g.Wn = (bf16_t*)Wn;
     g.ldw = K;
-    return gemm_launch(g, stream);
+    return slim_gemm_launch(g, stream);
 }
 
 // ---- bf16 transpose through a padded LDS tile ----------------------------------------------
@@ -389,7 +383,7 @@ extern "C" int slim_gram_accum(const void* x, int64_t T, int64_t K, int64_t ld, 
         g.beta = first ? beta : 1.f;
         g.C32 = H;
         g.ldc32 = K;
-        int rc = gemm_launch(g, stream);
+        int rc = slim_gemm_launch(g, stream);
         if (rc) return rc;
         first = false;
     }

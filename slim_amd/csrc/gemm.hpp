@@ -1,0 +1,43 @@
+// Argument block of the NT bf16 MFMA GEMM (gemm.hip), shared with the low-rank fit, which issues strided
+// batches of it.
+#pragma once
+#include "common.hpp"
+
+struct GemmArgs {
+    const bf16_t* A = nullptr;
+    int64_t lda = 0;
+    const bf16_t* B = nullptr;
+    int64_t ldb = 0;
+    int M = 0, N = 0, Kd = 0;
+    float alpha = 1.f, beta = 0.f;  // C32 = alpha * acc + beta * C32 (beta = 0: C32 is not read)
+    float* C32 = nullptr;
+    int64_t ldc32 = 0;
+    bf16_t* C16 = nullptr;
+    int64_t ldc16 = 0;
+    bf16_t* Ct16 = nullptr;
+    int64_t ldct = 0;
+    // optional fused epilogue of the adapter subtraction (slim/lora.py:199-201):
+    // Wn = mask ? 0 : bf16(float(W) - float(bf16(acc)))
+    const bf16_t* W = nullptr;
+    const uint8_t* mask = nullptr;
+    bf16_t* Wn = nullptr;
+    int64_t ldw = 0;
+    // split-K: gridDim.y slices of the reduction; slice z writes its fp32 partial tile to slab[z][M][N]
+    // (no other output), summed afterwards in slice order by splitk_reduce_kernel
+    int splits = 0, ksteps_per_split = 0;
+    float* slab = nullptr;
+    // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
+    int batch = 1;
+    int64_t sA = 0, sB = 0, sC32 = 0, sC16 = 0, sCt = 0, sSlab = 0;
+};
+
+// Launch (and, for splits > 1, reduce).  Split-K callers fill splits / ksteps_per_split through
+// gemm_plan_splits.
+int slim_gemm_launch(const GemmArgs& g, void* stream);
+inline void gemm_plan_splits(GemmArgs& g, int splits) {
+    const int nk = (g.Kd + 63) / 64;
+    if (splits > nk) splits = nk;
+    if (splits < 1) splits = 1;
+    g.ksteps_per_split = (nk + splits - 1) / splits;
+    g.splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
+}

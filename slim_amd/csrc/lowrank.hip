@@ -13,6 +13,7 @@
 //   outputs: U [N, r], Ut [r, N] (= lora_right), L [K, r] (= lora_left = V_r S_r), S [r]
 #include "common.hpp"
 #include "../../include/slim_hip.h"
+#include "gemm.hpp"
 #include <dlfcn.h>
 #include <mutex>
 #include <map>
@@ -28,6 +29,9 @@ typedef int (*fn_set_stream)(rb_handle, hipStream_t);
 typedef int (*fn_potrf)(rb_handle, int, int, float*, int, int*);
 typedef int (*fn_trtri)(rb_handle, int, int, int, float*, int, int*);
 typedef int (*fn_syevd)(rb_handle, int, int, int, float*, int, float*, float*, int*);
+typedef int (*fn_potrf_sb)(rb_handle, int, int, float*, int, int64_t, int*, int);
+typedef int (*fn_trtri_sb)(rb_handle, int, int, int, float*, int, int64_t, int*, int);
+typedef int (*fn_syevd_sb)(rb_handle, int, int, int, float*, int, int64_t, float*, int64_t, float*, int64_t, int*, int);
 
 struct Solver {
     bool ok = false;
@@ -36,6 +40,9 @@ struct Solver {
     fn_potrf potrf = nullptr;
     fn_trtri trtri = nullptr;
     fn_syevd syevd = nullptr;
+    fn_potrf_sb potrf_sb = nullptr;      // strided-batched variants: one launch chain for a whole batch
+    fn_trtri_sb trtri_sb = nullptr;
+    fn_syevd_sb syevd_sb = nullptr;
     std::map<std::pair<int, hipStream_t>, rb_handle> handles;  // per (device, stream): rocSOLVER keeps device workspace in the handle
     std::mutex mu;
 };
@@ -52,6 +59,9 @@ int solver_init() {
         g_solver.potrf = (fn_potrf)dlsym(h, "rocsolver_spotrf");
         g_solver.trtri = (fn_trtri)dlsym(h, "rocsolver_strtri");
         g_solver.syevd = (fn_syevd)dlsym(h, "rocsolver_ssyevd");
+        g_solver.potrf_sb = (fn_potrf_sb)dlsym(h, "rocsolver_spotrf_strided_batched");
+        g_solver.trtri_sb = (fn_trtri_sb)dlsym(h, "rocsolver_strtri_strided_batched");
+        g_solver.syevd_sb = (fn_syevd_sb)dlsym(h, "rocsolver_ssyevd_strided_batched");
         g_solver.ok = g_solver.create && g_solver.set_stream && g_solver.potrf && g_solver.trtri && g_solver.syevd;
     });
     if (!g_solver.ok) {
@@ -87,6 +97,8 @@ int solver_handle(hipStream_t st, rb_handle* out) {
 }  // namespace
 
 // ---- small kernels -----------------------------------------------------------------------------
+// Every kernel below works on a strided batch of identical problems: the last grid dimension in use selects
+// the problem, `stride` arguments are in elements.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352du;
@@ -96,8 +108,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
-// standard-normal bf16 test matrix from a counter-based hash (Box-Muller on two 24-bit uniforms)
-__global__ void randn_bf16_kernel(bf16_t* __restrict__ out, int64_t n, uint32_t seed) {
+// standard-normal bf16 test matrix from a counter-based hash (Box-Muller on two 24-bit uniforms); every
+// problem of a batch (blockIdx.y) receives the same matrix, so a batched fit equals the single fits
+__global__ void randn_bf16_kernel(bf16_t* __restrict__ out, int64_t n, uint32_t seed, int64_t stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t a = mix32((uint32_t)i * 2u + 0x9e3779b9u * (seed + 1u));
@@ -105,7 +118,7 @@ __global__ void randn_bf16_kernel(bf16_t* __restrict__ out, int64_t n, uint32_t 
     const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
     const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
     const float z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
-    out[i] = f32_to_bf16(z);
+    out[(int64_t)blockIdx.y * stride + i] = f32_to_bf16(z);
 }
 
 // rocSOLVER works column-major; an l x l buffer holding inv(R) column-major (R upper) reads
@@ -113,13 +126,15 @@ __global__ void randn_bf16_kernel(bf16_t* __restrict__ out, int64_t n, uint32_t 
 __global__ void tri_to_bf16_kernel(const float* __restrict__ a, int l, bf16_t* __restrict__ out) {
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;  // row-major (i, j)
     if (j >= l) return;
-    out[(int64_t)i * l + j] = j <= i ? f32_to_bf16(a[(int64_t)i * l + j]) : (bf16_t)0;
+    const int64_t o = (int64_t)blockIdx.z * l * l + (int64_t)i * l + j;
+    out[o] = j <= i ? f32_to_bf16(a[o]) : (bf16_t)0;
 }
 
 // add a small multiple of the mean diagonal to the Gram matrix so Cholesky cannot break down on a
 // numerically rank-deficient iterate (the perturbed basis is re-orthonormalised again later)
 __global__ void ridge_kernel(float* __restrict__ g, int l, float rel) {
     __shared__ float red[4];
+    g += (int64_t)blockIdx.x * l * l;
     float s = 0.f;
     for (int i = threadIdx.x; i < l; i += 256) s += g[(int64_t)i * l + i];
     s = wave_sum(s);
@@ -134,42 +149,58 @@ __global__ void ridge_kernel(float* __restrict__ g, int l, float rel) {
 // row-major view is eigenvector i.  Emit the top r, largest first, as bf16 [r, l], and S = sqrt(max(w, 0)).
 __global__ void top_eigvecs_kernel(const float* __restrict__ vecs, const float* __restrict__ w, int l, int r,
                                    bf16_t* __restrict__ out, float* __restrict__ S) {
+    const int64_t bz = blockIdx.z;
     const int j = blockIdx.y;  // output row
     const int src = l - 1 - j;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < l) out[(int64_t)j * l + c] = f32_to_bf16(vecs[(int64_t)src * l + c]);
-    if (c == 0 && S) S[j] = sqrtf(fmaxf(w[src], 0.f));
+    if (c < l) out[bz * l * l + (int64_t)j * l + c] = f32_to_bf16(vecs[bz * l * l + (int64_t)src * l + c]);
+    if (c == 0 && S) S[bz * r + j] = sqrtf(fmaxf(w[bz * l + src], 0.f));
 }
 
 // lora_left = bf16(bf16(L) / bf16(s[k])) row-wise (slim/lora.py:193-195)
 __global__ void scale_rows_kernel(bf16_t* __restrict__ L, const float* __restrict__ s, int64_t K, int64_t r) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * r) return;
+    L += (int64_t)blockIdx.y * K * r;
+    s += (int64_t)blockIdx.y * K;
     const int64_t k = i / r;
     const float d = round_bf16(s[k]);
     L[i] = f32_to_bf16(bf16_to_f32(L[i]) / d);
 }
 
+// status words of a batched solver call (one per problem) into word `idx` of each problem's info block
+__global__ void info_scatter_kernel(const int* __restrict__ tmp, int batch, int* __restrict__ info, int idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) info[b * SLIM_FIT_INFO_WORDS + idx] = tmp[b];
+}
+
 extern "C" int slim_randn_bf16(void* out, int64_t n, uint32_t seed, void* stream) {
     SLIM_REQUIRE(out && n > 0, "slim_randn_bf16: bad arguments");
-    randn_bf16_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)out, n, seed);
+    randn_bf16_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)out, n, seed, 0);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+static int scale_rows_batched(void* L, const float* s, int64_t K, int64_t r, int batch, void* stream) {
+    dim3 grid((unsigned)ceil_div64(K * r, 256), (unsigned)batch);
+    scale_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((bf16_t*)L, s, K, r);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
 
 extern "C" int slim_scale_rows_bf16(void* L, const float* s, int64_t K, int64_t r, void* stream) {
     SLIM_REQUIRE(L && s && K > 0 && r > 0, "slim_scale_rows_bf16: bad arguments");
-    scale_rows_kernel<<<(unsigned)ceil_div64(K * r, 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)L, s, K, r);
-    SLIM_LAUNCH_CHECK();
-    return SLIM_OK;
+    return scale_rows_batched(L, s, K, r, 1, stream);
 }
 
 // ---- Newton-Schulz helper kernels ------------------------------------------------------------------
 // scal[0] = 1 / sqrt(||G||_F): after X <- scal * X every singular value of X is <= 1 (and >= l^(-1/4)
 // of the largest), the range in which the polynomial iteration below is stable.
 #define FRO_BLOCKS 64
+#define SCAL_STRIDE 4
 __global__ __launch_bounds__(256) void fro_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
     __shared__ double red[4];
+    g += (int64_t)blockIdx.y * n;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)FRO_BLOCKS * 256) {
         const double v = (double)g[i];
@@ -178,13 +209,13 @@ __global__ __launch_bounds__(256) void fro_partial_kernel(const float* __restric
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) part[blockIdx.y * FRO_BLOCKS + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ __launch_bounds__(64) void fro_rsqrt_kernel(const double* __restrict__ part, float* __restrict__ scal) {
-    const double t = wave_sum_d(part[threadIdx.x]);
+    const double t = wave_sum_d(part[blockIdx.x * FRO_BLOCKS + threadIdx.x]);
     if (threadIdx.x == 0) {
         const double fro = sqrt(t);
-        scal[0] = fro > 0.0 ? (float)(1.0 / sqrt(fro)) : 1.0f;
+        scal[blockIdx.x * SCAL_STRIDE] = fro > 0.0 ? (float)(1.0 / sqrt(fro)) : 1.0f;
     }
 }
 
@@ -193,9 +224,9 @@ __global__ void ns_poly_kernel(const float* __restrict__ G, const float* __restr
                                float a, float b, float q, int l, bf16_t* __restrict__ P) {
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= l) return;
-    const float c = scal ? scal[0] : 1.f;
+    const float c = scal ? scal[blockIdx.z * SCAL_STRIDE] : 1.f;
     const float c2 = c * c;
-    const int64_t o = (int64_t)i * l + j;
+    const int64_t o = (int64_t)blockIdx.z * l * l + (int64_t)i * l + j;
     float v = b * c2 * G[o] + (q != 0.f ? q * c2 * c2 * G2[o] : 0.f);
     if (i == j) v += a;
     P[o] = f32_to_bf16(c * v);
@@ -206,29 +237,32 @@ __global__ void ns_poly_kernel(const float* __restrict__ G, const float* __restr
 static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 
 struct Pair {
-    bf16_t *X, *Xt;  // [rows, l] and its transpose [l, rows]
+    bf16_t *X, *Xt;  // [batch][rows, l] and its transpose [batch][l, rows]
 };
 struct FitWs {
+    int batch;
     Pair A[3];      // row-side iterates (rows = N): Y / Q, rotating
     Pair B[3];      // column-side iterates (rows = K): Z / P, rotating
-    float* G;       // [l, l] Gram matrix / Cholesky factor / eigenvectors
-    float* G2;      // [l, l] square of the Gram matrix
-    bf16_t* G16;    // [l, l] bf16 copy of G
-    bf16_t* T16;    // [l, l] polynomial / inv(R)^T, later [r, l] leading eigenvectors
-    float* evals;   // [l]
-    float* ework;   // [l]
-    float* scal;    // [4]
-    double* fro_part;  // [FRO_BLOCKS] partial sums of squares
-    float* slab;    // [GRAM_MAX_SPLITS, l, l] split-K partials of the Gram products
-    int* info;      // [SLIM_FIT_INFO_WORDS]
+    float* G;       // [batch][l, l] Gram matrix / Cholesky factor / eigenvectors
+    float* G2;      // [batch][l, l] square of the Gram matrix
+    bf16_t* G16;    // [batch][l, l] bf16 copy of G
+    bf16_t* T16;    // [batch][l, l] polynomial / inv(R)^T, later [r, l] leading eigenvectors
+    float* evals;   // [batch][l]
+    float* ework;   // [batch][l]
+    float* scal;    // [batch][SCAL_STRIDE]
+    double* fro_part;  // [batch][FRO_BLOCKS] partial sums of squares
+    float* slab;    // [batch][GRAM_MAX_SPLITS, l, l] split-K partials of the Gram products
+    int* info;      // [batch][SLIM_FIT_INFO_WORDS]
+    int* info_tmp;  // [batch] status words of one batched solver call
     int64_t total;
 };
-static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
+static FitWs fit_ws(char* base, int batch, int64_t N, int64_t K, int64_t l) {
     FitWs w;
+    w.batch = batch;
     int64_t o = 0;
     auto take = [&](int64_t bytes) {
         char* p = base ? base + o : nullptr;
-        o += al256(bytes);
+        o += al256(bytes * batch);
         return p;
     };
     for (int i = 0; i < 3; ++i) {
@@ -245,28 +279,21 @@ static FitWs fit_ws(char* base, int64_t N, int64_t K, int64_t l) {
     w.T16 = (bf16_t*)take(l * l * 2);
     w.evals = (float*)take(l * 4);
     w.ework = (float*)take(l * 4);
-    w.scal = (float*)take(16);
+    w.scal = (float*)take(SCAL_STRIDE * 4);
     w.fro_part = (double*)take(FRO_BLOCKS * 8);
     w.slab = (float*)take((int64_t)GRAM_MAX_SPLITS * l * l * 4);
     w.info = (int*)take(SLIM_FIT_INFO_WORDS * 4);
+    w.info_tmp = (int*)take(4);
     w.total = o;
     return w;
 }
 
-extern "C" int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l) {
-    if (N <= 0 || K <= 0 || l <= 0) return 0;
-    return fit_ws(nullptr, N, K, l).total;
+extern "C" int64_t slim_lowrank_fit_batched_workspace_bytes(int batch, int64_t N, int64_t K, int64_t l) {
+    if (batch <= 0 || N <= 0 || K <= 0 || l <= 0) return 0;
+    return fit_ws(nullptr, batch, N, K, l).total;
 }
-
-// G (fp32) and optionally G16 (bf16) <- Xt Xt^T, reduction over `rows` split so that tiles * splits covers the chip
-static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, void* stream) {
-    const int tiles = ((l + 127) / 128) * ((l + 127) / 128);
-    int splits = (512 + tiles - 1) / tiles;
-    const int nk = (int)((rows + 63) / 64);
-    if (splits > nk / 4) splits = nk / 4;      // at least four K-steps per slice
-    if (splits > GRAM_MAX_SPLITS) splits = GRAM_MAX_SPLITS;
-    if (splits < 1) splits = 1;
-    return slim_gemm_nt_bf16_splitk(Xt, rows, Xt, rows, l, l, (int)rows, 1.f, w.G, l, G16, l, splits, w.slab, stream);
+extern "C" int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l) {
+    return slim_lowrank_fit_batched_workspace_bytes(1, N, K, l);
 }
 
 #define CHK(x)                 \
@@ -275,29 +302,108 @@ static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, vo
         if (rc__) return rc__; \
     } while (0)
 
+// Strided-batched NT product: C[b] = A[b] (M x Kd, row stride lda) * Bt[b]^T (N x Kd, row stride ldb); a
+// stride of 0 shares the operand between the problems.  Outputs as in slim_gemm_nt_bf16.
+static int nt(int batch, const bf16_t* A, int64_t lda, int64_t sA, const bf16_t* Bt, int64_t ldb, int64_t sB, int M, int N,
+              int Kd, float* C32, bf16_t* C16, int64_t ldc, bf16_t* Ct16, int64_t ldct, void* stream) {
+    GemmArgs g;
+    g.A = A;
+    g.lda = lda;
+    g.B = Bt;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.Kd = Kd;
+    g.C32 = C32;
+    g.ldc32 = ldc;
+    g.C16 = C16;
+    g.ldc16 = ldc;
+    g.Ct16 = Ct16;
+    g.ldct = ldct;
+    g.batch = batch;
+    g.sA = sA;
+    g.sB = sB;
+    g.sC32 = g.sC16 = g.sCt = (int64_t)M * N;
+    return slim_gemm_launch(g, stream);
+}
+
+// G (fp32) and optionally G16 (bf16) <- Xt Xt^T per problem, reduction over `rows` split so that tiles * splits
+// covers the chip.  The split count depends on the shape only (not on the batch size), so a batched fit adds its
+// partial sums in the same order as a single one.
+static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, void* stream) {
+    const int tiles = ((l + 127) / 128) * ((l + 127) / 128);
+    int splits = (512 + tiles - 1) / tiles;
+    const int nk = (int)((rows + 63) / 64);
+    if (splits > nk / 4) splits = nk / 4;      // at least four K-steps per slice
+    if (splits > GRAM_MAX_SPLITS) splits = GRAM_MAX_SPLITS;
+    if (splits < 1) splits = 1;
+    GemmArgs g;
+    g.A = Xt;
+    g.lda = rows;
+    g.B = Xt;
+    g.ldb = rows;
+    g.M = l;
+    g.N = l;
+    g.Kd = (int)rows;
+    g.C32 = w.G;
+    g.ldc32 = l;
+    g.C16 = G16;
+    g.ldc16 = l;
+    g.batch = w.batch;
+    g.sA = g.sB = rows * l;
+    g.sC32 = g.sC16 = (int64_t)l * l;
+    g.slab = w.slab;
+    g.sSlab = (int64_t)GRAM_MAX_SPLITS * l * l;
+    gemm_plan_splits(g, splits);
+    return slim_gemm_launch(g, stream);
+}
+
+static int scatter_info(FitWs& w, int idx, hipStream_t st) {
+    info_scatter_kernel<<<(w.batch + 63) / 64, 64, 0, st>>>(w.info_tmp, w.batch, w.info, idx);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 // Cholesky-QR: dst <- orthonormal basis of the column space of src (G = X^T X = R^T R, Q = X inv(R)),
-// rocSOLVER potrf + trtri on the l x l factor.
-static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, FitWs& w, int* info, void* stream) {
+// rocSOLVER potrf + trtri on the l x l factors (one strided-batched call chain for the whole batch).
+static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, FitWs& w, int info_idx, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     rb_handle h = nullptr;
     CHK(solver_handle(st, &h));
     CHK(gram(src.Xt, rows, l, w, nullptr, stream));
-    ridge_kernel<<<1, 256, 0, st>>>(w.G, l, 1e-6f);
+    ridge_kernel<<<w.batch, 256, 0, st>>>(w.G, l, 1e-6f);
     SLIM_LAUNCH_CHECK();
-    int solver_tok = g_slim_prof_on ? slim_prof_begin("solver_potrf_trtri", st, 0.0, (double)l * l * l) : -1;
-    if (g_solver.potrf(h, RB_FILL_UPPER, l, w.G, l, info) != 0) {
-        slim_set_error("rocsolver_spotrf failed");
-        return SLIM_ERR_SOLVER;
-    }
-    if (g_solver.trtri(h, RB_FILL_UPPER, RB_DIAG_NON_UNIT, l, w.G, l, info + 1) != 0) {
-        slim_set_error("rocsolver_strtri failed");
-        return SLIM_ERR_SOLVER;
+    int solver_tok = g_slim_prof_on ? slim_prof_begin("solver_potrf_trtri", st, 0.0, (double)l * l * l * w.batch) : -1;
+    const int64_t sG = (int64_t)l * l;
+    if (w.batch > 1 && g_solver.potrf_sb && g_solver.trtri_sb) {
+        if (g_solver.potrf_sb(h, RB_FILL_UPPER, l, w.G, l, sG, w.info_tmp, w.batch) != 0) {
+            slim_set_error("rocsolver_spotrf_strided_batched failed");
+            return SLIM_ERR_SOLVER;
+        }
+        CHK(scatter_info(w, info_idx, st));
+        if (g_solver.trtri_sb(h, RB_FILL_UPPER, RB_DIAG_NON_UNIT, l, w.G, l, sG, w.info_tmp, w.batch) != 0) {
+            slim_set_error("rocsolver_strtri_strided_batched failed");
+            return SLIM_ERR_SOLVER;
+        }
+        CHK(scatter_info(w, info_idx + 1, st));
+    } else {
+        for (int b = 0; b < w.batch; ++b) {
+            int* info = w.info + b * SLIM_FIT_INFO_WORDS + info_idx;
+            if (g_solver.potrf(h, RB_FILL_UPPER, l, w.G + b * sG, l, info) != 0) {
+                slim_set_error("rocsolver_spotrf failed");
+                return SLIM_ERR_SOLVER;
+            }
+            if (g_solver.trtri(h, RB_FILL_UPPER, RB_DIAG_NON_UNIT, l, w.G + b * sG, l, info + 1) != 0) {
+                slim_set_error("rocsolver_strtri failed");
+                return SLIM_ERR_SOLVER;
+            }
+        }
     }
     if (solver_tok >= 0) slim_prof_end(solver_tok, st);
-    dim3 grid((unsigned)((l + 255) / 256), (unsigned)l);
+    dim3 grid((unsigned)((l + 255) / 256), (unsigned)l, (unsigned)w.batch);
     tri_to_bf16_kernel<<<grid, 256, 0, st>>>(w.G, l, w.T16);
     SLIM_LAUNCH_CHECK();
-    return slim_gemm_nt_bf16(src.X, l, w.T16, l, (int)rows, l, l, 1.f, 0.f, nullptr, 0, dst.X, l, dst.Xt, rows, stream);
+    return nt(w.batch, src.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, dst.X, l, dst.Xt, rows, stream);
 }
 
 // Newton-Schulz orthonormalisation on MFMA: X <- X p(X^T X) keeps the column space and drives every
@@ -307,26 +413,25 @@ static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, Fi
 // bufs[cur] holds the input; returns the index of the buffer holding the result.
 static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, FitWs& w, void* stream, int* out_idx) {
     hipStream_t st = (hipStream_t)stream;
-    const dim3 pgrid((unsigned)((l + 255) / 256), (unsigned)l);
+    const dim3 pgrid((unsigned)((l + 255) / 256), (unsigned)l, (unsigned)w.batch);
+    const int64_t sG = (int64_t)l * l;
     for (int sidx = 0; sidx < nq + nc; ++sidx) {
         const bool quintic = sidx < nq;
         const Pair& x = bufs[cur];
         const int nxt = (cur + 1) % 3;
         CHK(gram(x.Xt, rows, l, w, w.G16, stream));
         if (sidx == 0) {
-            fro_partial_kernel<<<FRO_BLOCKS, 256, 0, st>>>(w.G, (int64_t)l * l, w.fro_part);
+            fro_partial_kernel<<<dim3(FRO_BLOCKS, w.batch), 256, 0, st>>>(w.G, sG, w.fro_part);
             SLIM_LAUNCH_CHECK();
-            fro_rsqrt_kernel<<<1, 64, 0, st>>>(w.fro_part, w.scal);
+            fro_rsqrt_kernel<<<w.batch, 64, 0, st>>>(w.fro_part, w.scal);
             SLIM_LAUNCH_CHECK();
         }
-        if (quintic)
-            CHK(slim_gemm_nt_bf16(w.G16, l, w.G16, l, l, l, l, 1.f, 0.f, w.G2, l, nullptr, 0, nullptr, 0, stream));
+        if (quintic) CHK(nt(w.batch, w.G16, l, sG, w.G16, l, sG, l, l, l, w.G2, nullptr, l, nullptr, 0, stream));
         ns_poly_kernel<<<pgrid, 256, 0, st>>>(w.G, w.G2, sidx == 0 ? w.scal : nullptr, quintic ? 3.4445f : 1.5f,
                                               quintic ? -4.7750f : -0.5f, quintic ? 2.0315f : 0.f, l, w.T16);
         SLIM_LAUNCH_CHECK();
         // P is symmetric, so it serves as its own transpose in the NT product X P
-        CHK(slim_gemm_nt_bf16(x.X, l, w.T16, l, (int)rows, l, l, 1.f, 0.f, nullptr, 0, bufs[nxt].X, l, bufs[nxt].Xt, rows,
-                              stream));
+        CHK(nt(w.batch, x.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, bufs[nxt].X, l, bufs[nxt].Xt, rows, stream));
         cur = nxt;
     }
     *out_idx = cur;
@@ -334,11 +439,11 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
 }
 
 // one orthonormalisation in the selected mode; cur/out index the rotating buffers
-static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, int nq, FitWs& w, int* info,
+static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, int nq, FitWs& w, int info_idx,
                 void* stream, int* out_idx) {
     if (flags & SLIM_FIT_CHOLESKY_QR) {
         const int nxt = (cur + 1) % 3;
-        CHK(cholesky_qr(bufs[cur], bufs[nxt], rows, l, w, info, stream));
+        CHK(cholesky_qr(bufs[cur], bufs[nxt], rows, l, w, info_idx, stream));
         *out_idx = nxt;
         return SLIM_OK;
     }
@@ -349,15 +454,14 @@ static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int f
     int mid = cur;
     CHK(ns_orth(bufs, cur, rows, l, nq, 0, w, stream, &mid));
     const int nxt = (mid + 1) % 3;
-    CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info, stream));
+    CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
     *out_idx = nxt;
     return SLIM_OK;
 }
 
-// Orthonormal basis (Q [rows, l], Qt [l, rows]) of the column space of X [rows, l] (Xt its transpose).
 extern "C" int64_t slim_orthonormalize_workspace_bytes(int64_t rows, int64_t l) {
     if (rows <= 0 || l <= 0) return 0;
-    return fit_ws(nullptr, rows, 8, l).total;
+    return fit_ws(nullptr, 1, rows, 8, l).total;
 }
 
 extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t rows, int l, int flags, int ns_quintic,
@@ -368,14 +472,14 @@ extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t r
                  "slim_orthonormalize_bf16: rows and l must be multiples of 8 with l <= rows");
     SLIM_REQUIRE(workspace_bytes >= slim_orthonormalize_workspace_bytes(rows, l), "slim_orthonormalize_bf16: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    FitWs w = fit_ws((char*)workspace, rows, 8, l);
+    FitWs w = fit_ws((char*)workspace, 1, rows, 8, l);
     const size_t bytes = (size_t)rows * l * sizeof(bf16_t);
     SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
     SLIM_HIP(hipMemcpyAsync(w.A[0].X, X, bytes, hipMemcpyDeviceToDevice, st));
     SLIM_HIP(hipMemcpyAsync(w.A[0].Xt, Xt, bytes, hipMemcpyDeviceToDevice, st));
     int a = 0;
     if (flags & SLIM_FIT_CHOLESKY_QR) {
-        CHK(cholesky_qr(w.A[0], w.A[1], rows, l, w, w.info, stream));
+        CHK(cholesky_qr(w.A[0], w.A[1], rows, l, w, 0, stream));
         a = 1;
     } else {
         CHK(ns_orth(w.A, 0, rows, l, ns_quintic, ns_cubic, w, stream, &a));
@@ -387,64 +491,102 @@ extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t r
     return SLIM_OK;
 }
 
-extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,
-                                uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S,
-                                int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
+// `batch` fits of identical shape in lockstep: E [batch][N, K], Et [batch][K, N], s [batch][K] (or NULL),
+// outputs U [batch][N, r], Ut [batch][r, N], L [batch][K, r], S [batch][r], info_out [batch][SLIM_FIT_INFO_WORDS].
+// Every launch covers the whole batch (gridDim.z / strided-batched solver calls), so the launch count and the
+// length of the dependent chain are those of ONE fit.  Each problem's result is bit-identical to a single fit
+// wherever the solver's batched and single routines agree.
+extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l,
+                                        int n_iter, uint32_t seed, int flags, int ns_steps, const float* s, void* U,
+                                        void* Ut, void* L, float* S, int32_t* info_out, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
     SLIM_REQUIRE(E && Et && U && L && workspace, "slim_lowrank_fit: null pointer");
+    SLIM_REQUIRE(batch >= 1 && batch <= 1024, "slim_lowrank_fit: batch must be in [1, 1024]");
     SLIM_REQUIRE(N > 0 && K > 0 && r > 0 && l >= r && n_iter >= 0, "slim_lowrank_fit: bad sizes");
     SLIM_REQUIRE(l <= N && l <= K, "slim_lowrank_fit: subspace dimension l exceeds min(N, K)");
     SLIM_REQUIRE(N % 8 == 0 && K % 8 == 0 && l % 8 == 0 && r % 8 == 0,
                  "slim_lowrank_fit: N, K, l, r must be multiples of 8");
     SLIM_REQUIRE(2 * (n_iter + 1) + 1 <= SLIM_FIT_INFO_WORDS / 2, "slim_lowrank_fit: too many iterations");
-    SLIM_REQUIRE(workspace_bytes >= slim_lowrank_fit_workspace_bytes(N, K, l), "slim_lowrank_fit: workspace too small");
+    SLIM_REQUIRE(workspace_bytes >= slim_lowrank_fit_batched_workspace_bytes(batch, N, K, l), "slim_lowrank_fit: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     rb_handle h = nullptr;
     CHK(solver_handle(st, &h));
-    FitWs w = fit_ws((char*)workspace, N, K, l);
-    SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    FitWs w = fit_ws((char*)workspace, batch, N, K, l);
+    SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
     const bf16_t* Eb = (const bf16_t*)E;
     const bf16_t* Etb = (const bf16_t*)Et;
+    const int64_t sE = N * K, sYn = N * l, sZk = K * l, sG = (int64_t)l * l;
     int ninfo = 0, a = 0, b = 0;
     const int nq = ns_steps > 0 ? (ns_steps > 16 ? 16 : ns_steps) : 4;
     // when the subspace is the whole space the basis must be orthonormal to working precision in every
     // direction, however weak: take the exact factorisation
     if (l == N || l == K) flags |= SLIM_FIT_CHOLESKY_QR;
 
+    // Y^T = P0^T E^T  (A = P0^T [l, K], Bt = E [N, K]) -> Y^T [l, N] and Y [N, l]
+    auto sketch_rows = [&](const bf16_t* Pt) {
+        return nt(batch, Pt, K, sZk, Eb, K, sE, l, (int)N, (int)K, nullptr, w.A[0].Xt, N, w.A[0].X, l, stream);
+    };
+    // Z^T = Q^T E  (A = Q^T [l, N], Bt = E^T [K, N]) -> Z^T [l, K] and Z [K, l]
+    auto sketch_cols = [&](const bf16_t* Qt) {
+        return nt(batch, Qt, N, sYn, Etb, N, sE, l, (int)K, (int)N, nullptr, w.B[0].Xt, K, w.B[0].X, l, stream);
+    };
+
     // P0^T [l, K]: Gaussian test matrix;  Y = E P0;  Q = orth(Y)
-    CHK(slim_randn_bf16(w.B[0].Xt, (int64_t)l * K, seed, stream));
-    CHK(slim_gemm_nt_bf16(w.B[0].Xt, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A[0].Xt, N, w.A[0].X, l, stream));
-    CHK(orth(w.A, 0, N, l, n_iter == 0, flags, nq, w, w.info + ninfo, stream, &a));
+    {
+        const int64_t n = (int64_t)l * K;
+        randn_bf16_kernel<<<dim3((unsigned)ceil_div64(n, 256), (unsigned)batch), 256, 0, st>>>(w.B[0].Xt, n, seed, sZk);
+        SLIM_LAUNCH_CHECK();
+    }
+    CHK(sketch_rows(w.B[0].Xt));
+    CHK(orth(w.A, 0, N, l, n_iter == 0, flags, nq, w, ninfo, stream, &a));
     ninfo += 2;
     for (int it = 0; it < n_iter; ++it) {
         // Z = E^T Q ; P = orth(Z)
-        CHK(slim_gemm_nt_bf16(w.A[a].Xt, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B[0].Xt, K, w.B[0].X, l, stream));
-        CHK(orth(w.B, 0, K, l, false, flags, nq, w, w.info + ninfo, stream, &b));
+        CHK(sketch_cols(w.A[a].Xt));
+        CHK(orth(w.B, 0, K, l, false, flags, nq, w, ninfo, stream, &b));
         ninfo += 2;
         // Y = E P ; Q = orth(Y)
-        CHK(slim_gemm_nt_bf16(w.B[b].Xt, K, Eb, K, l, (int)N, (int)K, 1.f, 0.f, nullptr, 0, w.A[0].Xt, N, w.A[0].X, l, stream));
-        CHK(orth(w.A, 0, N, l, it == n_iter - 1, flags, nq, w, w.info + ninfo, stream, &a));
+        CHK(sketch_rows(w.B[b].Xt));
+        CHK(orth(w.A, 0, N, l, it == n_iter - 1, flags, nq, w, ninfo, stream, &a));
         ninfo += 2;
     }
     // Rayleigh-Ritz: B = Q^T E (kept as B^T = Z [K, l]); M = B B^T = W diag(S^2) W^T
-    CHK(slim_gemm_nt_bf16(w.A[a].Xt, N, Etb, N, l, (int)K, (int)N, 1.f, 0.f, nullptr, 0, w.B[0].Xt, K, w.B[0].X, l, stream));
+    CHK(sketch_cols(w.A[a].Xt));
     CHK(gram(w.B[0].Xt, K, l, w, nullptr, stream));
-    int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l) : -1;
-    if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, w.evals, w.ework, w.info + ninfo) != 0) {
-        slim_set_error("rocsolver_ssyevd failed");
-        return SLIM_ERR_SOLVER;
+    int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l * batch) : -1;
+    if (batch > 1 && g_solver.syevd_sb) {
+        if (g_solver.syevd_sb(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, sG, w.evals, l, w.ework, l, w.info_tmp, batch) != 0) {
+            slim_set_error("rocsolver_ssyevd_strided_batched failed");
+            return SLIM_ERR_SOLVER;
+        }
+        CHK(scatter_info(w, ninfo, st));
+    } else {
+        for (int bi = 0; bi < batch; ++bi)
+            if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G + bi * sG, l, w.evals + (int64_t)bi * l,
+                               w.ework + (int64_t)bi * l, w.info + bi * SLIM_FIT_INFO_WORDS + ninfo) != 0) {
+                slim_set_error("rocsolver_ssyevd failed");
+                return SLIM_ERR_SOLVER;
+            }
     }
     ninfo += 1;
     if (syevd_tok >= 0) slim_prof_end(syevd_tok, st);
     {
-        dim3 grid((unsigned)((l + 255) / 256), (unsigned)r);
+        dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
         top_eigvecs_kernel<<<grid, 256, 0, st>>>(w.G, w.evals, l, r, w.T16, S);
         SLIM_LAUNCH_CHECK();
     }
     // L = V_r S_r = B^T W_r  [K, r];  U = Q W_r  [N, r] (+ U^T = lora_right)
-    CHK(slim_gemm_nt_bf16(w.B[0].X, l, w.T16, l, (int)K, r, l, 1.f, 0.f, nullptr, 0, L, r, nullptr, 0, stream));
-    CHK(slim_gemm_nt_bf16(w.A[a].X, l, w.T16, l, (int)N, r, l, 1.f, 0.f, nullptr, 0, U, r, Ut, N, stream));
-    if (s) CHK(slim_scale_rows_bf16(L, s, K, r, stream));
+    CHK(nt(batch, w.B[0].X, l, sZk, w.T16, l, sG, (int)K, r, l, nullptr, (bf16_t*)L, r, nullptr, 0, stream));
+    CHK(nt(batch, w.A[a].X, l, sYn, w.T16, l, sG, (int)N, r, l, nullptr, (bf16_t*)U, r, (bf16_t*)Ut, N, stream));
+    if (s) CHK(scale_rows_batched(L, s, K, r, batch, stream));
     if (info_out)
-        SLIM_HIP(hipMemcpyAsync(info_out, w.info, SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+        SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
     return SLIM_OK;
+}
+
+extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,
+                                uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S,
+                                int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    return slim_lowrank_fit_batched(E, Et, 1, N, K, r, l, n_iter, seed, flags, ns_steps, s, U, Ut, L, S, info_out, workspace,
+                                    workspace_bytes, stream);
 }

@@ -152,14 +152,35 @@ def quantize_lora(model, bitwidth=8, lora_tile_size=256):
             lin.lora_quantizer = quantizer
 
 
-def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None, quantizer=None, prune_lora=False,
-             separate_lora=True, lora_tile_size=None, quantize_first=False, scale_important_weights=False):
-    """Fit low-rank adapters to the compression error of `module` and re-quantise the residual weight
-    (lora.py:105-213).  Sets module.lora_left [K, r], module.lora_right [r, N] and module.weight.data.
+class LoraContext:
+    """State of one layer between the three phases of add_lora (prepare -> fit -> finish)."""
 
-    Implemented: quantizer None or per-tensor (SLiM-Quant / abs-max), slim_lora on or off,
-    quantize_first=True, separate_lora=True.  Other flag combinations raise NotImplementedError.
-    """
+    def tensors(self):
+        out = [self.W, self.W_mask, self.s, self.E, self.Et]
+        if getattr(self, "fit", None) is not None:
+            out += list(self.fit)
+        if self.outliers is not None:
+            out.append(self.outliers[0])
+        return [t for t in out if isinstance(t, torch.Tensor)]
+
+    def touch(self):
+        """Tell the caching allocator that the current stream uses this layer's tensors (the phases of one
+        layer may run on different streams)."""
+        st = torch.cuda.current_stream()
+        for t in self.tensors():
+            t.record_stream(st)
+
+    def group_key(self):
+        """Layers with equal keys can be fitted in lockstep by one batched call."""
+        return (tuple(self.W.shape), self.rank, self.s is not None, self.outliers is None)
+
+
+def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None, quantizer=None, prune_lora=False,
+                     separate_lora=True, lora_tile_size=None, quantize_first=False, scale_important_weights=False,
+                     E_out=None, Et_out=None):
+    """First phase of add_lora (lora.py:105-169): argument checks, first quantisation, error matrix E (and its
+    transpose) -- written into E_out / Et_out when given, so that same-shape layers of a block sit in one
+    strided buffer for the batched fit."""
     if scale_important_weights:
         raise NotImplementedError("scale_important_weights is not implemented")
     if prune_lora:
@@ -173,45 +194,110 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     W = module.weight.data
     if W.dtype != torch.bfloat16 or not W.is_cuda:
         raise RuntimeError("add_lora expects a bf16 weight on the GPU")
-    W = W.contiguous()
-    N, K = W.shape
-    bits = quantizer.num_bits if quantizer is not None else 4
+    c = LoraContext()
+    c.module, c.quantizer, c.W_mask = module, quantizer, W_mask
+    c.W = W.contiguous()
+    N, K = c.W.shape
+    c.bits = quantizer.num_bits if quantizer is not None else 4
     has_zero = getattr(activations, "has_zero", None)       # precomputed by the driver (one sync per block)
     if has_zero is None:
         has_zero = ops.any_zero(activations.scaler_row)
     use_slim = bool(slim_lora) and not has_zero                                 # lora.py:139
-    s = ops.sqrt(activations.scaler_row) if use_slim else None
+    c.s = ops.sqrt(activations.scaler_row) if use_slim else None
 
     # first quantisation (scale search on W) and error matrix  (lora.py:146-156 / :158-169)
     sf1 = None
     if quantizer is not None:
-        sf1 = _weight_scale(W, quantizer).reshape(1)
-    _, E = ops.error_matrix(W, W_mask, s, sf1, bits)
-    Et = ops.transpose(E)
+        sf1 = _weight_scale(c.W, quantizer).reshape(1)
+    _, c.E = ops.error_matrix(c.W, W_mask, c.s, sf1, c.bits, out=E_out)
+    c.Et = ops.transpose(c.E, out=Et_out)
 
     rank = lora_rank((N, K), rank_ratio, lora_tile_size)
-    rank = min(rank, min(N, K))      # S[:rank] of a min(N, K)-long spectrum (lora.py:184)
+    c.rank = min(rank, min(N, K))      # S[:rank] of a min(N, K)-long spectrum (lora.py:184)
     if use_slim:
         outliers, spread = getattr(activations, "outliers", "unset"), getattr(activations, "scale_spread", None)
         if spread is None or isinstance(outliers, str):      # not precomputed by the driver
             outliers, spread = outlier_columns(activations.scaler_row)
     else:
         outliers, spread = None, 1.0
-    U, lora_right, lora_left, fit_info = fit_error_matrix(E, Et, rank, s, outliers, spread)
-    del E, Et
+    c.outliers, c.spread = outliers, spread
+    c.fit = None
+    return c
 
-    # residual weight W - R^T L^T, masked (lora.py:199-201), then second quantisation (:202-204)
-    new_weight = ops.lowrank_residual(U, lora_left, W, W_mask)
+
+def planned_group_key(module, rank_ratio, lora_tile_size, slim_lora, activations):
+    """LoraContext.group_key() of a layer before it is prepared (needs activations.has_zero / .outliers)."""
+    N, K = module.weight.shape
+    rank = min(lora_rank((N, K), rank_ratio, lora_tile_size), min(N, K))
+    use_slim = bool(slim_lora) and not activations.has_zero
+    return ((N, K), rank, use_slim, (not use_slim) or activations.outliers is None)
+
+
+def add_lora_fit(ctxs, E_group=None, Et_group=None):
+    """Second phase: the low-rank fit (lora.py:172-195).  Contexts whose E / Et are the slices, in order, of
+    E_group [B, N, K] / Et_group [B, K, N] are fitted in lockstep by one batched call; otherwise one by one."""
+    if E_group is None or len(ctxs) == 1:
+        for c in ctxs:
+            c.touch()
+            c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s, c.outliers, c.spread)
+        return
+    assert len({c.group_key() for c in ctxs}) == 1 and ctxs[0].outliers is None and E_group.shape[0] == len(ctxs)
+    for c in ctxs:
+        c.touch()
+    rank = ctxs[0].rank
+    r8 = _round_up8(rank)
+    N, K = ctxs[0].W.shape
+    over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
+    s = torch.stack([c.s for c in ctxs]).contiguous() if ctxs[0].s is not None else None
+    fit = ops.lowrank_fit(E_group, Et_group, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
+                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=max(ns_steps_for(c.spread) for c in ctxs))
+    U, Ut, L = fit["U"], fit["Ut"], fit["L"]
+    if U.shape[-1] != r8:
+        raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+    if r8 != rank:
+        U[..., rank:] = 0
+        Ut[:, rank:] = 0
+        L[..., rank:] = 0
+    for b, c in enumerate(ctxs):
+        c.fit = (U[b], Ut[b], L[b], fit["info"][b])
+
+
+def add_lora_finish(c):
+    """Third phase (lora.py:199-209): residual weight W - R^T L^T, masked, second quantisation; sets
+    module.lora_left [K, r], module.lora_right [r, N], module.weight.data.  Returns the second scaling
+    factor (fp32 (1, 1)) or None; it is also left in quantizer.scaling_factor like the reference does."""
+    c.touch()
+    U, lora_right, lora_left, fit_info = c.fit
+    module, quantizer, rank = c.module, c.quantizer, c.rank
+    new_weight = ops.lowrank_residual(U, lora_left, c.W, c.W_mask)
+    sf_out = None
     if quantizer is not None:
         sf2 = _weight_scale(new_weight, quantizer)
-        new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), bits)
-        quantizer.scaling_factor = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
+        new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), c.bits)
+        sf_out = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
+        quantizer.scaling_factor = sf_out
     if lora_left.shape[1] != rank:       # the factors are padded to a multiple of 8 columns
         lora_left, lora_right = lora_left[:, :rank], lora_right[:rank]
     module.lora_left = torch.nn.Parameter(lora_left).to(torch.bfloat16).contiguous()
     module.lora_right = torch.nn.Parameter(lora_right).to(torch.bfloat16).contiguous()
     module.weight.data = new_weight.to(torch.bfloat16).contiguous()
     module.lora_fit_info = fit_info
+    return sf_out
+
+
+def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None, quantizer=None, prune_lora=False,
+             separate_lora=True, lora_tile_size=None, quantize_first=False, scale_important_weights=False):
+    """Fit low-rank adapters to the compression error of `module` and re-quantise the residual weight
+    (lora.py:105-213).  Sets module.lora_left [K, r], module.lora_right [r, N] and module.weight.data.
+
+    Implemented: quantizer None or per-tensor (SLiM-Quant / abs-max), slim_lora on or off,
+    quantize_first=True, separate_lora=True.  Other flag combinations raise NotImplementedError.
+    The driver runs the three phases separately so that same-shape layers share one batched fit.
+    """
+    c = add_lora_prepare(module, W_mask, rank_ratio, slim_lora, activations, quantizer, prune_lora, separate_lora,
+                         lora_tile_size, quantize_first, scale_important_weights)
+    add_lora_fit([c])
+    add_lora_finish(c)
 
 
 def _weight_scale(W, quantizer):

@@ -158,20 +158,28 @@ def fake_quant_pt(W, sf, num_bits, want_codes=False):
 
 
 # ---- low-rank fit ----------------------------------------------------------------------------
-def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True):
+def _out_or_new(out, shape, device, name):
+    if out is None:
+        return torch.empty(*shape, dtype=BF16, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != BF16 or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError(f"{name}: `out` must be a contiguous bf16 GPU tensor of shape {tuple(shape)}")
+    return out
+
+
+def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=None):
     W = _chk(W, BF16, "W")
     mask = _chk(mask, torch.bool, "mask")
     N, K = W.shape
     e32 = torch.empty(N, K, dtype=torch.float32, device=W.device) if want_f32 else None
-    e16 = torch.empty(N, K, dtype=BF16, device=W.device) if want_bf16 else None
+    e16 = _out_or_new(out, (N, K), W.device, "error_matrix") if want_bf16 else None
     _lib.call("slim_error_matrix", _p(W), _p(mask), _p(s), _p(sf), num_bits, N, K, _p(e32), _p(e16), _stream())
     return e32, e16
 
 
-def transpose(x):
+def transpose(x, out=None):
     x = _chk(x, BF16, "x")
     R, Cc = x.shape
-    out = torch.empty(Cc, R, dtype=BF16, device=x.device)
+    out = _out_or_new(out, (Cc, R), x.device, "transpose")
     _lib.call("slim_transpose_bf16", _p(x), R, Cc, _p(out), _stream())
     return out
 
@@ -221,23 +229,34 @@ def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
 
 
 def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0):
-    """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info)."""
+    """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info).
+    E [B, N, K] (with Et [B, K, N], s [B, K]) runs B fits of identical shape in lockstep and returns
+    tensors with a leading batch dimension."""
     E = _chk(E, BF16, "E")
     Et = _chk(Et, BF16, "Et")
-    N, K = E.shape
+    batched = E.dim() == 3
+    B = E.shape[0] if batched else 1
+    N, K = E.shape[-2:]
+    if tuple(Et.shape) != ((B, K, N) if batched else (K, N)):
+        raise ValueError("Et must be the transpose of E")
     l = min(r + oversample, N, K)
     l -= l % 8
     if r > l:
         raise ValueError(f"rank {r} exceeds the usable subspace dimension {l} of a {N}x{K} matrix")
+    if s is not None:
+        s = _chk(s, torch.float32, "s")
+        if s.numel() != B * K:
+            raise ValueError("s must hold one scale per input channel (and per problem)")
     dev = E.device
-    U = torch.empty(N, r, dtype=BF16, device=dev)
-    Ut = torch.empty(r, N, dtype=BF16, device=dev)
-    L = torch.empty(K, r, dtype=BF16, device=dev)
-    S = torch.empty(r, dtype=torch.float32, device=dev)
-    info = torch.empty(64, dtype=torch.int32, device=dev)
-    ws = _ws(_lib.query("slim_lowrank_fit_workspace_bytes", N, K, l), dev)
-    _lib.call("slim_lowrank_fit", _p(E), _p(Et), N, K, r, l, n_iter, seed, int(bool(cholesky_qr)), int(ns_steps), _p(s), _p(U), _p(Ut), _p(L), _p(S),
-              _p(info), _p(ws), ws.numel(), _stream())
+    lead = (B,) if batched else ()
+    U = torch.empty(*lead, N, r, dtype=BF16, device=dev)
+    Ut = torch.empty(*lead, r, N, dtype=BF16, device=dev)
+    L = torch.empty(*lead, K, r, dtype=BF16, device=dev)
+    S = torch.empty(*lead, r, dtype=torch.float32, device=dev)
+    info = torch.empty(*lead, 64, dtype=torch.int32, device=dev)
+    ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", B, N, K, l), dev)
+    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)), int(ns_steps),
+              _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
 

@@ -16,7 +16,7 @@ import tqdm.auto as tqdm
 from . import ops
 from .data import get_loaders
 from .layerwrapper import WrappedGPT
-from .lora import add_lora
+from .lora import add_lora  # noqa: F401  (re-exported: slim.prune.add_lora in the reference)
 from .quantization.quantization import Quantizer as AutoQuantizer, QuantizedMatmul
 from .utils import get_layers_list, find_layers
 
@@ -31,6 +31,10 @@ LAYER_CALLBACK = None
 # phases of the other linears.  Each stream is fed by its own host thread (run_on_streams); 7 = one per linear
 # of a LLaMA block.  1 = everything on the current stream.
 COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "7"))
+# Fit same-shape linears of a block (q/k/v/o, gate/up) in lockstep with one batched call.  Off by default: the
+# batched eigen-solver of rocSOLVER takes as long as the single ones one after the other, and separate fits
+# overlap their solver chains on different streams, which is faster as long as that solver is on the path.
+BATCH_FITS = os.environ.get("SLIM_BATCH_FITS", "0") == "1"
 _side_streams = {}
 
 
@@ -186,6 +190,124 @@ def _run_block(layer, src, dst, kwargs, batch):
             dst[j:j + batch] = out
 
 
+def compress_linears(items, dev, prune_n, prune_m, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
+                     quantize_lora=False, pad_lora=False, lora_tile_size=256, separate_lora=True, quantize_first=True,
+                     scale_important_weights=False, tiled_weight_quantization=False, callback=None, describe=None,
+                     n_streams=None):
+    """Compress the linears of one block after their statistics pass (the body of the per-linear loop of
+    prune.py:256-357).  items: list of (name, nn.Linear, WrappedGPT) with block_stats() already applied.
+
+    With adapters the work runs in three phases, each spread over the side streams: (1) per linear: mask,
+    first scale search, error matrix; (2) per group of same-shape linears (q/k/v/o, gate/up): ONE batched
+    low-rank fit, so the launch count and the eigen-solve chain are paid once per group; (3) per linear:
+    residual weight, second scale search, re-quantisation, adapter attributes and hook."""
+    from .lora import (add_lora_prepare, add_lora_fit, add_lora_finish, planned_group_key)
+
+    def mask_of(lin, wrapped):
+        if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
+            W_mask = lin.weight.mask.to(dev)
+            del lin.weight.mask
+            return W_mask
+        return ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), prune_n, prune_m)
+
+    def produced(lin):
+        return [lin.weight.data, getattr(lin, "scaling_factor", None)] + \
+               [p.data for p in (getattr(lin, "lora_left", None), getattr(lin, "lora_right", None)) if p is not None]
+
+    if not lora_rank > 0.:
+        def plain(name, lin, wrapped):
+            if describe:
+                describe(name)
+            W_mask = mask_of(lin, wrapped)
+            # prune.py:330-357, quantize_first branch: quantise the dense weight, then zero the mask
+            if not quantize_first:
+                raise NotImplementedError("quantize_first=False is not implemented")
+            if quantizer is not None:
+                codes = quantizer.quantize_weight(lin.weight.data)
+                lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
+                lin.scaling_factor = quantizer.scaling_factor
+            lin.weight.data[W_mask] = 0
+            if callback is not None:
+                callback(name, lin, wrapped)
+            return produced(lin)
+        # the shared quantizer keeps its last scale as state, so these jobs stay on one thread
+        run_on_streams([lambda it=it: plain(*it) for it in items], dev, 1)
+        return
+
+    tile = lora_tile_size if (quantize_lora or pad_lora) else None
+    # groups of linears whose fits can run in lockstep, with one strided E / E^T buffer per group
+    groups = {}
+    for idx, (name, lin, wrapped) in enumerate(items):
+        if getattr(wrapped, "has_zero", None) is None:
+            block_stats([wrapped])
+        groups.setdefault(planned_group_key(lin, lora_rank, tile, slim_lora, wrapped), []).append(idx)
+    slot, buffers = {}, {}
+    for key, members in groups.items():
+        (N, K), _, _, batchable = key
+        if BATCH_FITS and batchable and len(members) > 1:
+            buffers[key] = (torch.empty(len(members), N, K, dtype=torch.bfloat16, device=dev),
+                            torch.empty(len(members), K, N, dtype=torch.bfloat16, device=dev))
+            for b, idx in enumerate(members):
+                slot[idx] = (key, b)
+    ctxs = [None] * len(items)
+
+    def prepare(idx):
+        name, lin, wrapped = items[idx]
+        if describe:
+            describe(name)
+        E_out = Et_out = None
+        if idx in slot:
+            key, b = slot[idx]
+            E_out, Et_out = buffers[key][0][b], buffers[key][1][b]
+        c = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
+                             separate_lora, tile, quantize_first, scale_important_weights, E_out, Et_out)
+        ctxs[idx] = c
+        return c.tensors()
+
+    def fit(key, members):
+        if key in buffers:
+            add_lora_fit([ctxs[i] for i in members], *buffers[key])
+        else:
+            add_lora_fit([ctxs[i] for i in members])
+        return [t for i in members for t in ctxs[i].tensors()]
+
+    def finish(idx):
+        name, lin, wrapped = items[idx]
+        sf = add_lora_finish(ctxs[idx])
+        if quantizer is not None:
+            lin.scaling_factor = None if tiled_weight_quantization else sf
+        if separate_lora:
+            lin.lora_rank = torch.tensor(lin.lora_left.shape[1])
+            lin.lora_left = torch.nn.Parameter(lin.lora_left * torch.sqrt(lin.lora_rank))
+            lin.lora_right = torch.nn.Parameter(lin.lora_right * torch.sqrt(lin.lora_rank))
+            lin.register_forward_hook(add_lora_hook)
+        if callback is not None:
+            callback(name, lin, wrapped)
+        ctxs[idx] = None
+        return produced(lin)
+
+    if not buffers:
+        # nothing to fit in lockstep: the three phases of a linear run back to back on one stream, so the
+        # linears overlap freely (no barrier between the phases)
+        def whole(idx):
+            prepare(idx)
+            add_lora_fit([ctxs[idx]])
+            return finish(idx)
+        run_on_streams([lambda i=i: whole(i) for i in range(len(items))], dev, n_streams)
+        return
+    run_on_streams([lambda i=i: prepare(i) for i in range(len(items))], dev, n_streams)
+    # a group that cannot be batched (outlier deflation, a single member) is fitted member by member, each
+    # member as a job of its own
+    fit_jobs = []
+    for key, members in groups.items():
+        if key in buffers:
+            fit_jobs.append(lambda key=key, members=members: fit(key, members))
+        else:
+            fit_jobs += [lambda key=key, i=i: fit(key, [i]) for i in members]
+    run_on_streams(fit_jobs, dev, n_streams)
+    run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
+
+
 def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quantize_weight=False, bitwidth=4,
                 slim_quant=False, tiled_weight_quantization=False, weight_tile_size=256, shift_zero_metrics=True,
                 lora_rank=0., slim_lora=True, prune_lora=False, quantize_lora=False, lora_tile_size=256,
@@ -236,42 +358,13 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                 wrapped_layers[name].scaler_row = ops.shift_zeros(wrapped_layers[name].scaler_row)
         block_stats(list(wrapped_layers.values()))
 
-        def compress(name):
-            progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}")
-            lin, wrapped = subset[name], wrapped_layers[name]
-            if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
-                W_mask = lin.weight.mask.to(dev)
-                del lin.weight.mask
-            else:
-                W_mask = ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), prune_n, prune_m)
-
-            if lora_rank > 0.:
-                tile = lora_tile_size if (quantize_lora or pad_lora) else None
-                add_lora(lin, W_mask=W_mask, rank_ratio=lora_rank, slim_lora=slim_lora, activations=wrapped,
-                         quantizer=quantizer, prune_lora=prune_lora, separate_lora=separate_lora, lora_tile_size=tile,
-                         quantize_first=quantize_first, scale_important_weights=scale_important_weights)
-                if quantizer is not None:
-                    lin.scaling_factor = None if tiled_weight_quantization else quantizer.scaling_factor
-                if separate_lora:
-                    lin.lora_rank = torch.tensor(lin.lora_left.shape[1])
-                    lin.lora_left = torch.nn.Parameter(lin.lora_left * torch.sqrt(lin.lora_rank))
-                    lin.lora_right = torch.nn.Parameter(lin.lora_right * torch.sqrt(lin.lora_rank))
-                    lin.register_forward_hook(add_lora_hook)
-            else:
-                # prune.py:330-357, quantize_first branch: quantise the dense weight, then zero the mask
-                if not quantize_first:
-                    raise NotImplementedError("quantize_first=False is not implemented")
-                if quantizer is not None:
-                    codes = quantizer.quantize_weight(lin.weight.data)
-                    lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
-                    lin.scaling_factor = quantizer.scaling_factor
-                lin.weight.data[W_mask] = 0
-            if LAYER_CALLBACK is not None:
-                LAYER_CALLBACK(i, name, lin, wrapped)
-            return [lin.weight.data, getattr(lin, "scaling_factor", None)] + \
-                   [p.data for p in (getattr(lin, "lora_left", None), getattr(lin, "lora_right", None)) if p is not None]
-
-        run_on_streams([lambda name=name: compress(name) for name in subset], dev)
+        compress_linears(
+            [(name, subset[name], wrapped_layers[name]) for name in subset], dev, prune_n, prune_m, quantizer=quantizer,
+            lora_rank=lora_rank, slim_lora=slim_lora, prune_lora=prune_lora, quantize_lora=quantize_lora, pad_lora=pad_lora,
+            lora_tile_size=lora_tile_size, separate_lora=separate_lora, quantize_first=quantize_first,
+            scale_important_weights=scale_important_weights, tiled_weight_quantization=tiled_weight_quantization,
+            callback=(lambda name, lin, wrapped, i=i: LAYER_CALLBACK(i, name, lin, wrapped)) if LAYER_CALLBACK else None,
+            describe=lambda name, i=i: progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}"))
 
         progress_bar.set_description(f"Layer {i} - Evaluating Output")
         _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
