@@ -25,6 +25,7 @@ extern "C" {
 #define SLIM_HIP_ABI_VERSION 1
 #define SLIM_FIT_INFO_WORDS 64
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
+#define SLIM_FIT_ONE_SIDED 2   /* re-orthonormalise only the row-side iterate (once per full iteration) */
 
 int slim_abi_version(void);
 const char* slim_last_error(void); /* host string, valid until the next failing call on this thread */

@@ -543,7 +543,14 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     for (int it = 0; it < n_iter; ++it) {
         // Z = E^T Q ; P = orth(Z)
         CHK(sketch_cols(w.A[a].Xt));
-        CHK(orth(w.B, 0, K, l, false, flags, nq, w, ninfo, stream, &b));
+        if (flags & SLIM_FIT_ONE_SIDED) {
+            // Z goes into the next product as it is: only the row-side iterate is re-orthonormalised, once per
+            // full iteration (its conditioning is then the square of the matrix's within the subspace, which
+            // the caller's ns_steps has to cover)
+            b = 0;
+        } else {
+            CHK(orth(w.B, 0, K, l, false, flags, nq, w, ninfo, stream, &b));
+        }
         ninfo += 2;
         // Y = E P ; Q = orth(Y)
         CHK(sketch_rows(w.B[b].Xt));
