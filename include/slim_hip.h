@@ -50,6 +50,15 @@ int slim_scaler_row_accum(const void* x, int64_t n_chunks, int64_t rows_per_chun
                           int64_t batch_per_chunk, float* scaler_row, int64_t nsamples_before, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* The two halves of slim_scaler_row_accum as separate calls (sample-sharded multi-GPU runs; no counterpart in
+ * the reference, which is single-GPU): sumsq fp32 [n_chunks, K] = per-chunk column sums of squares;
+ * slim_scaler_row_fold applies the recurrence of layerwrapper.py:33-41 to such sums, chunk by chunk.
+ * colsumsq + (all-gather into sample order) + fold is bit-identical to slim_scaler_row_accum on all samples. */
+int slim_colsumsq(const void* x_bf16, int64_t n_chunks, int64_t rows_per_chunk, int64_t K, int64_t ld, float* sumsq,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+int slim_scaler_row_fold(float* scaler_row, int64_t K, const float* sumsq, int64_t n_chunks, int64_t batch_per_chunk,
+                         int64_t nsamples_before, void* stream);
+
 /* SparseGPT.add_batch, slim/sparsegpt.py:28-39: H = H * n/(n+b) + (2/(n+b)) * X^T X, fp32 [K, K],
  * X = [T, K] bf16 (T = b * tokens).  MFMA bf16 products, fp32 accumulation. */
 int64_t slim_gram_workspace_bytes(int64_t T, int64_t K);

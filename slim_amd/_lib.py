@@ -19,6 +19,8 @@ PROTOTYPES = {
     "slim_profile_summary": (i32, [C.c_char_p, i64]),
     "slim_colsumsq_workspace_bytes": (i64, [i64, i64, i64]),
     "slim_scaler_row_accum": (i32, [vp, i64, i64, i64, i64, i64, vp, i64, vp, i64, vp]),
+    "slim_colsumsq": (i32, [vp, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "slim_scaler_row_fold": (i32, [vp, i64, vp, i64, i64, i64, vp]),
     "slim_gram_workspace_bytes": (i64, [i64, i64]),
     "slim_gram_accum": (i32, [vp, i64, i64, i64, vp, i64, i64, vp, i64, vp]),
     "slim_shift_zeros": (i32, [vp, vp, i64, vp]),

@@ -103,6 +103,48 @@ extern "C" int slim_scaler_row_accum(const void* x, int64_t n_chunks, int64_t ro
 
 // ---- shift_zeros + sqrt ---------------------------------------------------------------
 // Single workgroup: m = min over (x == 0 ? 1 : x); out = x + m.  NaN propagates like torch.min.
+// sumsq[chunk][c] = slab partials of one chunk added in slab order (the order scaler_update_kernel uses)
+__global__ void fold_slabs_kernel(const float* __restrict__ partial, int64_t K, int slabs, float* __restrict__ sumsq) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    const int64_t ch = blockIdx.y;
+    float ss = 0.f;
+    for (int s = 0; s < slabs; ++s) ss += partial[(ch * slabs + s) * K + c];
+    sumsq[ch * K + c] = ss;
+}
+
+// The two halves of slim_scaler_row_accum as separate calls, for runs that shard the calibration samples over
+// several GPUs: every rank reduces its samples to per-sample column sums, the sums are all-gathered into
+// sample order, and every rank folds them with the same recurrence -- bit-identical to a single-GPU run.
+extern "C" int slim_colsumsq(const void* x, int64_t n_chunks, int64_t rows_per_chunk, int64_t K, int64_t ld, float* sumsq,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(x && sumsq && workspace, "slim_colsumsq: null pointer");
+    SLIM_REQUIRE(n_chunks > 0 && rows_per_chunk > 0 && K > 0, "slim_colsumsq: bad sizes");
+    SLIM_REQUIRE(K % 8 == 0 && ld % 8 == 0 && ld >= K && ((uintptr_t)x % 16) == 0,
+                 "slim_colsumsq: K and ld must be multiples of 8 and x 16-byte aligned");
+    SLIM_REQUIRE(workspace_bytes >= slim_colsumsq_workspace_bytes(n_chunks, rows_per_chunk, K), "slim_colsumsq: workspace too small");
+    const int slabs = (int)ceil_div64(rows_per_chunk, SLAB_ROWS);
+    SLIM_REQUIRE(n_chunks <= 65535 && slabs <= 65535, "slim_colsumsq: too many chunks/slabs for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    SLIM_PROF("colsumsq", stream, 2.0 * n_chunks * rows_per_chunk * K);
+    dim3 grid((unsigned)ceil_div64(K, 256 * 8), (unsigned)slabs, (unsigned)n_chunks);
+    colsumsq_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows_per_chunk, K, ld, (float*)workspace, slabs);
+    SLIM_LAUNCH_CHECK();
+    fold_slabs_kernel<<<dim3((unsigned)ceil_div64(K, 256), (unsigned)n_chunks), 256, 0, st>>>((const float*)workspace, K, slabs, sumsq);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+extern "C" int slim_scaler_row_fold(float* scaler_row, int64_t K, const float* sumsq, int64_t n_chunks,
+                                    int64_t batch_per_chunk, int64_t nsamples_before, void* stream) {
+    SLIM_REQUIRE(scaler_row && sumsq && K > 0 && n_chunks > 0 && batch_per_chunk > 0 && nsamples_before >= 0,
+                 "slim_scaler_row_fold: bad arguments");
+    scaler_update_kernel<<<(unsigned)ceil_div64(K, 256), 256, 0, (hipStream_t)stream>>>(scaler_row, K, sumsq, n_chunks, 1,
+                                                                                        batch_per_chunk, nsamples_before);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 __global__ __launch_bounds__(1024) void shift_zeros_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            int64_t K) {
     __shared__ float red[16];

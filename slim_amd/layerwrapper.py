@@ -13,7 +13,7 @@ class WrappedGPT:
     reference) is kept when `track_inp_sum=True`.
     """
 
-    def __init__(self, layer, layer_id=0, layer_name="none", track_inp_sum=False):
+    def __init__(self, layer, layer_id=0, layer_name="none", track_inp_sum=False, defer=False):
         self.layer = layer
         self.dev = self.layer.weight.device
         self.rows = layer.weight.data.shape[0]
@@ -25,6 +25,10 @@ class WrappedGPT:
         self.layer_id = layer_id
         self.layer_name = layer_name
         self.track_inp_sum = track_inp_sum
+        # defer=True: keep the per-sample column sums instead of folding them into scaler_row; a run that
+        # shards the samples over several GPUs gathers them into sample order first (finish_deferred)
+        self.defer = defer
+        self.sample_sums = []
 
     def add_batch(self, inp, out=None, per_sample=False):
         """One forward call's input `inp` ([B, S, K] or [S, K], bf16).
@@ -46,8 +50,23 @@ class WrappedGPT:
         self.inp_num += b if per_sample else 1
         if flat.dtype != torch.bfloat16:
             raise TypeError("WrappedGPT.add_batch expects bf16 activations")
-        if per_sample:
+        if self.defer:
+            if not per_sample:
+                raise ValueError("deferred statistics are kept per sample")
+            self.sample_sums.append(ops.colsumsq(flat, n_chunks=b))
+        elif per_sample:
             ops.scaler_row_accum(flat, self.scaler_row, self.nsamples, n_chunks=b, batch_per_chunk=1)
         else:
             ops.scaler_row_accum(flat, self.scaler_row, self.nsamples, n_chunks=1, batch_per_chunk=b)
         self.nsamples += b
+
+    def finish_deferred(self, gather=None):
+        """Fold the kept per-sample sums (after `gather`, e.g. parallel.gather_sample_stats, has put the sums
+        of all ranks into sample order) into scaler_row with the reference's recurrence."""
+        sums = torch.cat(self.sample_sums, 0)
+        self.sample_sums = []
+        if gather is not None:
+            sums = gather(sums)
+        ops.scaler_row_fold(self.scaler_row, sums, 0, batch_per_chunk=1)
+        self.nsamples = sums.shape[0]
+        self.inp_num = sums.shape[0]

@@ -49,6 +49,28 @@ def scaler_row_accum(x, scaler_row, nsamples_before, n_chunks, batch_per_chunk):
     return scaler_row
 
 
+def colsumsq(x, n_chunks):
+    """Per-chunk column sums of squares of x (bf16 [n_chunks * rows, K]) -> fp32 [n_chunks, K]."""
+    x = _chk(x, BF16, "x")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    rows = x2.shape[0] // n_chunks
+    assert rows * n_chunks == x2.shape[0]
+    out = torch.empty(n_chunks, K, dtype=torch.float32, device=x.device)
+    ws = _ws(_lib.query("slim_colsumsq_workspace_bytes", n_chunks, rows, K), x.device)
+    _lib.call("slim_colsumsq", _p(x2), n_chunks, rows, K, K, _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def scaler_row_fold(scaler_row, sumsq, nsamples_before, batch_per_chunk=1):
+    """Apply the scaler_row recurrence to per-chunk sums (fp32 [n_chunks, K]), in place."""
+    _chk(scaler_row, torch.float32, "scaler_row")
+    sumsq = _chk(sumsq, torch.float32, "sumsq")
+    n_chunks, K = sumsq.shape
+    _lib.call("slim_scaler_row_fold", _p(scaler_row), K, _p(sumsq), n_chunks, batch_per_chunk, int(nsamples_before), _stream())
+    return scaler_row
+
+
 def gram_accum(x, H, nsamples_before, batch):
     x = _chk(x, BF16, "x")
     _chk(H, torch.float32, "H")

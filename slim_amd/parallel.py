@@ -25,7 +25,22 @@ def linear_cost(n, k):
     return float(n) * float(k)
 
 
-def exchange_linear(lin, owner, rank, shapes, device, group=None):
+def _staged(group):
+    """gloo moves host memory only: stage device tensors through the host (CPU tests, single-GPU rehearsals)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def broadcast(t, src, group=None):
+    if t.is_cuda and _staged(group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True):
     """Broadcast one compressed linear from its owner.  shapes = (N, K, r).  Non-owners allocate receive
     buffers; afterwards every rank holds weight.data [N, K], lora_left [K, r], lora_right [r, N] and
     scaling_factor (1, 1)."""
@@ -35,9 +50,9 @@ def exchange_linear(lin, owner, rank, shapes, device, group=None):
         lin.weight.data = torch.empty(N, K, dtype=dt, device=device)
         lin.lora_left = torch.nn.Parameter(torch.empty(K, r, dtype=dt, device=device), requires_grad=False)
         lin.lora_right = torch.nn.Parameter(torch.empty(r, N, dtype=dt, device=device), requires_grad=False)
-        lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=device)
-    for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data, lin.scaling_factor):
-        dist.broadcast(t, src=owner, group=group)
+        lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=device) if has_scale else None
+    for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data) + ((lin.scaling_factor,) if has_scale else ()):
+        broadcast(t, owner, group)
     return lin
 
 
@@ -46,6 +61,19 @@ def gather_sample_stats(local_sumsq, group=None):
     [n_local * world, K], so that every rank can apply the scaler_row recurrence in the same order as a
     single-GPU run.  Rank r is expected to hold samples r * n_local ... (r + 1) * n_local - 1."""
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(local_sumsq) for _ in range(world)]
-    dist.all_gather(parts, local_sumsq.contiguous(), group=group)
+    src = local_sumsq.contiguous()
+    if src.is_cuda and _staged(group):
+        h = src.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.cat(parts, 0).to(src.device)
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
     return torch.cat(parts, 0)
+
+
+def world_info(group=None):
+    """(rank, world_size) of the initialised process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1

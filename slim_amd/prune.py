@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import tqdm.auto as tqdm
 
-from . import ops
+from . import ops, parallel
 from .data import get_loaders
 from .layerwrapper import WrappedGPT
 from .lora import add_lora  # noqa: F401  (re-exported: slim.prune.add_lora in the reference)
@@ -308,6 +308,28 @@ def compress_linears(items, dev, prune_n, prune_m, quantizer=None, lora_rank=0.,
     run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
 
 
+def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale):
+    """Every rank receives the compressed form of the linears it does not own (weight, adapters, scale) and gives
+    them the attributes and the hook the owner's copy has."""
+    from .lora import lora_rank as rank_of
+    for j, n in enumerate(names):
+        lin = subset[n]
+        N, K = lin.weight.shape
+        if lora_rank > 0.:
+            r = min(rank_of((N, K), lora_rank, lora_tile_size if tiled_rank else None), min(N, K))
+            mine = owner[j] == rank
+            parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale)
+            if not mine:
+                lin.lora_rank = torch.tensor(r)
+                lin.register_forward_hook(add_lora_hook)
+        else:
+            parallel.broadcast(lin.weight.data, owner[j])
+            if has_scale:
+                if owner[j] != rank:
+                    lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=dev)
+                parallel.broadcast(lin.scaling_factor, owner[j])
+
+
 def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quantize_weight=False, bitwidth=4,
                 slim_quant=False, tiled_weight_quantization=False, weight_tile_size=256, shift_zero_metrics=True,
                 lora_rank=0., slim_lora=True, prune_lora=False, quantize_lora=False, lora_tile_size=256,
@@ -329,6 +351,17 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
     with torch.no_grad():
         inps, outs, kwargs = prepare_calibration_input(model, dataloader, nsamples, device=dev)
     kwargs = _to_device(kwargs, dev)
+    # Several GPUs (one process each, torch.distributed initialised by the caller): every rank keeps a contiguous
+    # share of the calibration samples and runs the block forwards on it; per-sample statistics are gathered into
+    # sample order, so scaler_row is bit-identical to a single-GPU run; the linears of a block are compressed by
+    # their owners (cost-balanced) and broadcast, so every rank holds the whole compressed block again.
+    rank, world = parallel.world_info()
+    if world > 1:
+        if nsamples % world != 0:
+            raise ValueError(f"nsamples ({nsamples}) must be divisible by the number of ranks ({world})")
+        n_local = nsamples // world
+        inps = inps[rank * n_local:(rank + 1) * n_local].clone()
+        outs = outs[rank * n_local:(rank + 1) * n_local].clone()
 
     quantizer = AutoQuantizer("weight", num_bits=bitwidth, slim_quant=slim_quant,
                               block_quantization=tiled_weight_quantization,
@@ -339,7 +372,7 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         progress_bar.set_description(f"Layer {i} - Gathering data")
         layer = layers[i].to(dev)
         subset = find_layers(layer)
-        wrapped_layers = {name: WrappedGPT(subset[name]) for name in subset}
+        wrapped_layers = {name: WrappedGPT(subset[name], defer=world > 1) for name in subset}
 
         def add_batch(name):
             def tmp(_, inp, out):
@@ -353,18 +386,28 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
 
         # shift_zeros (prune.py:261-262), then the `any(scaler_row == 0)` guard of add_lora (lora.py:139, which
         # sees the shifted statistics) for every linear with a single host synchronisation
+        if world > 1:
+            for name in subset:
+                wrapped_layers[name].finish_deferred(parallel.gather_sample_stats)
         if shift_zero_metrics:
             for name in subset:
                 wrapped_layers[name].scaler_row = ops.shift_zeros(wrapped_layers[name].scaler_row)
         block_stats(list(wrapped_layers.values()))
 
+        names = list(subset)
+        owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)
         compress_linears(
-            [(name, subset[name], wrapped_layers[name]) for name in subset], dev, prune_n, prune_m, quantizer=quantizer,
+            [(n, subset[n], wrapped_layers[n]) for j, n in enumerate(names) if owner[j] == rank], dev, prune_n, prune_m,
+            quantizer=quantizer,
             lora_rank=lora_rank, slim_lora=slim_lora, prune_lora=prune_lora, quantize_lora=quantize_lora, pad_lora=pad_lora,
             lora_tile_size=lora_tile_size, separate_lora=separate_lora, quantize_first=quantize_first,
             scale_important_weights=scale_important_weights, tiled_weight_quantization=tiled_weight_quantization,
             callback=(lambda name, lin, wrapped, i=i: LAYER_CALLBACK(i, name, lin, wrapped)) if LAYER_CALLBACK else None,
             describe=lambda name, i=i: progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}"))
+
+        if world > 1:
+            _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
+                            quantizer is not None and not tiled_weight_quantization)
 
         progress_bar.set_description(f"Layer {i} - Evaluating Output")
         _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)

@@ -1,0 +1,64 @@
+"""The sample-sharded, layer-partitioned driver (two ranks, gloo, both on the one GPU of the test box) must leave
+exactly what the single-process driver leaves: statistics are gathered into sample order before the recurrence
+and every linear is compressed by exactly one rank with the same kernels, so the result is bit-identical."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from transformers import LlamaConfig, LlamaForCausalLM
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+torch.manual_seed(0)
+m = LlamaForCausalLM(LlamaConfig(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                                 num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=32)).to(torch.bfloat16).eval()
+m.config.max_position_embeddings = 32
+import slim_amd.prune as P
+g = torch.Generator().manual_seed(1)
+calib = [(torch.randint(0, 256, (1, 32), generator=g), None) for _ in range(8)]
+P.get_loaders = lambda *a, **k: (calib, None)
+P.KEEP_ON_DEVICE = True
+P.prune_and_quantize(m, None, bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5, sparsity_type="2:4",
+                     quantize_weight=True, nsamples=8, lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=128)
+out = {}
+from slim_amd.utils import get_layers_list, find_layers
+for i, layer in enumerate(get_layers_list(m)):
+    for name, lin in find_layers(layer).items():
+        out[f"{i}.{name}.weight"] = lin.weight.data.cpu()
+        out[f"{i}.{name}.L"] = lin.lora_left.data.cpu()
+        out[f"{i}.{name}.R"] = lin.lora_right.data.cpu()
+        out[f"{i}.{name}.sf"] = lin.scaling_factor.cpu()
+        assert int(lin.lora_rank) == lin.lora_left.shape[1] and len(lin._forward_hooks) == 1
+if int(os.environ.get("RANK", "0")) == 0:
+    torch.save(out, sys.argv[2])
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_equal_one(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    subprocess.run([sys.executable, str(worker), ROOT, one], check=True, env=env, timeout=300)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                    "127.0.0.1", "--master-port", "29611", str(worker), ROOT, two], check=True, env=env, timeout=300)
+    a, b = torch.load(one), torch.load(two)
+    assert a.keys() == b.keys() and len(a) == 2 * 7 * 4
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
