@@ -142,7 +142,7 @@ def main():
             lins[i]._forward_hooks.clear()
         # the per-linear body of slim_amd.prune.prune_wanda after the statistics pass
         compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in mine], dev, 2, 4,
-                         quantizer=Quantizer("weight", num_bits=4, slim_quant=True), lora_rank=0.1, slim_lora=True,
+                         sparsity_ratio=0.5, quantizer=Quantizer("weight", num_bits=4, slim_quant=True), lora_rank=0.1, slim_lora=True,
                          quantize_lora=True, lora_tile_size=256, n_streams=args.streams)
         if world > 1:
             # exchange step: every rank receives the compressed shards of the linears it does not own

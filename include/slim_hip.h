@@ -82,6 +82,13 @@ int slim_mask_nm(const void* W_bf16, const float* s, int64_t N, int64_t K, int n
                  void* stream);
 /* prune_nm on an arbitrary fp32 metric matrix, slim/utils.py:75-88. */
 int slim_prune_nm_f32(const float* metric, int64_t N, int64_t K, int n, int m, uint8_t* mask, void* stream);
+
+/* Unstructured Wanda pruning, slim/prune.py:264-265 + :275-279: per row the k_prune = int(K * sparsity_ratio)
+ * smallest saliencies |W| * s are marked (1 = pruned), ties to the lower index (stable sort), NaN last.
+ * Rows of up to 40448 elements (the row's keys are held in LDS).  The _f32 form takes a ready metric. */
+int slim_mask_unstructured(const void* W_bf16, const float* s, int64_t N, int64_t K, int64_t k_prune, uint8_t* mask,
+                           void* stream);
+int slim_prune_unstructured_f32(const float* metric, int64_t N, int64_t K, int64_t k_prune, uint8_t* mask, void* stream);
 /* HOST: the 729-entry tie table of the 4-wide selection (index = base-3 digits of the six pairwise
  * comparisons 01,02,03,12,13,23 with 0: <, 1: ==, 2: >; value = bit i set if element i is selected). */
 int slim_nm_lut4(int n, uint8_t* out729_host);
@@ -123,6 +130,10 @@ int slim_fake_quant_pt(const void* W_bf16, int64_t numel, const float* sf, int n
  * Written as fp32 and/or bf16 (either pointer may be NULL). */
 int slim_error_matrix(const void* W_bf16, const uint8_t* mask, const float* s, const float* sf, int num_bits,
                       int64_t N, int64_t K, float* E_f32, void* E_bf16, void* stream);
+/* Same with the dequantised weight given as a bf16 tensor (tiled group quantiser, lora.py:149-150 with
+ * block_quantization): E = W * s - mask0(Wdeq * s). */
+int slim_error_matrix_deq(const void* W_bf16, const void* Wdeq_bf16, const uint8_t* mask, const float* s, int64_t N,
+                          int64_t K, float* E_f32, void* E_bf16, void* stream);
 
 int slim_transpose_bf16(const void* in, int64_t R, int64_t C, void* out, void* stream);
 

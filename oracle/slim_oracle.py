@@ -87,6 +87,28 @@ def prune_nm(mat, n, m):
     return mask.reshape(N, K)
 
 
+def prune_unstructured(mat, sparsity_ratio):
+    """slim/prune.py:275-279: per row, a stable ascending sort and the first int(K * ratio) indices pruned."""
+    order = torch.sort(mat.float(), dim=-1, stable=True)[1]
+    idx = order[:, :int(mat.shape[1] * sparsity_ratio)]
+    mask = torch.zeros(mat.shape, dtype=torch.bool)
+    mask.scatter_(1, idx, True)
+    return mask
+
+
+def compress_linear_plain(W, W_mask, num_bits=4, quantize_first=True):
+    """slim/prune.py:330-357 with a per-tensor SLiM-Quant quantizer and no adapters: quantise then mask, or mask
+    then quantise.  Returns (weight bf16, scaling factor)."""
+    W = W.clone()
+    if not quantize_first:
+        W[W_mask] = 0
+    codes, sf = quantize_per_tensor(W, num_bits, slim_quant=True)
+    out = dequantize_per_tensor(codes, sf).to(torch.bfloat16)
+    if quantize_first:
+        out[W_mask] = 0
+    return out, sf
+
+
 # --------------------------------------------------------------------------------------
 # SLiM-Quant: histogram scale search + per-tensor symmetric quantisation
 # --------------------------------------------------------------------------------------

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "slim_any_zero_f32": (i32, [vp, i64, vp, vp]),
     "slim_mask_nm": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
     "slim_prune_nm_f32": (i32, [vp, i64, i64, i32, i32, vp, vp]),
+    "slim_mask_unstructured": (i32, [vp, vp, i64, i64, i64, vp, vp]),
+    "slim_prune_unstructured_f32": (i32, [vp, i64, i64, i64, vp, vp]),
     "slim_nm_lut4": (i32, [i32, vp]),
     "slim_hist_abs_bf16": (i32, [vp, i64, vp, i32, vp]),
     "slim_quant_search_workspace_bytes": (i64, [i32]),
@@ -37,6 +39,7 @@ PROTOTYPES = {
     "slim_dequantize_pt": (i32, [vp, i64, vp, vp, i32, vp]),
     "slim_fake_quant_pt": (i32, [vp, i64, vp, i32, vp, vp, vp]),
     "slim_error_matrix": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
+    "slim_error_matrix_deq": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp]),
     "slim_transpose_bf16": (i32, [vp, i64, i64, vp, vp]),
     "slim_gemm_nt_bf16": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, f32, vp, i64, vp, i64, vp, i64, vp]),
     "slim_orthonormalize_workspace_bytes": (i64, [i64, i64]),

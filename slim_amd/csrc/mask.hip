@@ -227,3 +227,114 @@ extern "C" int slim_prune_nm_f32(const float* metric, int64_t N, int64_t K, int 
                                  void* stream) {
     return launch_mask(metric, false, nullptr, N, K, n, m, mask, stream);
 }
+
+// ---- unstructured (per-row) pruning -------------------------------------------------------------
+// slim/prune.py:275-279: per output row, a stable ascending sort of the saliency and the first
+// int(K * sparsity_ratio) indices pruned, i.e. the k smallest with ties going to the lower index; NaN
+// sorts last and -0 equals +0, as in torch.sort.  One workgroup per row: the row's keys sit in LDS, a
+// 4-pass radix select finds the k-th smallest key, and an ordered count settles the ties at that key.
+__device__ __forceinline__ uint32_t sort_key(float v) {
+    if (v != v) return 0xffffffffu;
+    uint32_t b = __float_as_uint(v);
+    if (b == 0x80000000u) b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+template <bool FROM_BF16>
+__global__ __launch_bounds__(256) void mask_unstructured_kernel(const void* __restrict__ src, const float* __restrict__ s,
+                                                                int64_t K, int64_t k_prune, uint8_t* __restrict__ mask) {
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* keys = lds_u32;
+    uint32_t* hist = lds_u32 + K;      // 256 bins
+    uint32_t* scan = hist + 256;       // 256 per-thread counts
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    for (int64_t i = tid; i < K; i += 256) {
+        float v;
+        if (FROM_BF16) {
+            const bf16_t w = ((const bf16_t*)src)[row * K + i];
+            v = bf16_to_f32((bf16_t)(w & 0x7fffu)) * s[i];
+        } else {
+            v = ((const float*)src)[row * K + i];
+        }
+        keys[i] = sort_key(v);
+    }
+    uint32_t prefix = 0u, pmask = 0u;
+    uint32_t remaining = (uint32_t)k_prune;   // how many of the keys matching the prefix are still to be taken
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0u;
+        __syncthreads();
+        for (int64_t i = tid; i < K; i += 256) {
+            const uint32_t key = keys[i];
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        uint32_t cum = 0u, bin = 255u;
+        for (uint32_t b = 0; b < 256u; ++b) {    // every thread scans the same 256 counters (LDS broadcast)
+            const uint32_t h = hist[b];
+            if (cum + h >= remaining) {
+                bin = b;
+                break;
+            }
+            cum += h;
+        }
+        remaining -= cum;
+        prefix |= bin << (8 * pass);
+        pmask |= 0xffu << (8 * pass);
+        __syncthreads();
+    }
+    // keys < prefix are pruned; of the keys == prefix the first `remaining` in index order
+    const int64_t chunk = (K + 255) / 256;
+    const int64_t i0 = tid * chunk, i1 = (i0 + chunk < K) ? i0 + chunk : K;
+    uint32_t eq = 0u;
+    for (int64_t i = i0; i < i1; ++i) eq += keys[i] == prefix;
+    scan[tid] = eq;
+    __syncthreads();
+    uint32_t before = 0u;
+    for (int t = 0; t < tid; ++t) before += scan[t];
+    for (int64_t i = i0; i < i1; ++i) {
+        const uint32_t key = keys[i];
+        uint32_t m = key < prefix;
+        if (key == prefix) m = before++ < remaining;
+        keys[i] = m;
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < K; i += 256) mask[row * K + i] = (uint8_t)keys[i];
+}
+
+static int launch_unstructured(const void* src, bool from_bf16, const float* s, int64_t N, int64_t K, int64_t k_prune,
+                               uint8_t* mask, void* stream) {
+    SLIM_REQUIRE(src && mask && N > 0 && K > 0 && (!from_bf16 || s), "slim_mask_unstructured: bad arguments");
+    SLIM_REQUIRE(k_prune >= 0 && k_prune <= K, "slim_mask_unstructured: the number of pruned weights per row must be in [0, K]");
+    const int64_t lds = (K + 512) * 4;
+    if (lds > 160 * 1024) {
+        slim_set_error("slim_mask_unstructured: rows longer than %d elements are not supported", (160 * 1024 - 2048) / 4);
+        return SLIM_ERR_UNSUPPORTED;
+    }
+    SLIM_REQUIRE(N < ((int64_t)1 << 31), "slim_mask_unstructured: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    SLIM_PROF("mask_unstructured", stream, (double)N * K * (from_bf16 ? 3.0 : 5.0));
+    if (k_prune == 0) {
+        SLIM_HIP(hipMemsetAsync(mask, 0, (size_t)(N * K), st));
+        return SLIM_OK;
+    }
+    if (from_bf16) {
+        SLIM_HIP(slim_allow_dynamic_lds((const void*)mask_unstructured_kernel<true>, (int)lds));
+        mask_unstructured_kernel<true><<<(unsigned)N, 256, (size_t)lds, st>>>(src, s, K, k_prune, mask);
+    } else {
+        SLIM_HIP(slim_allow_dynamic_lds((const void*)mask_unstructured_kernel<false>, (int)lds));
+        mask_unstructured_kernel<false><<<(unsigned)N, 256, (size_t)lds, st>>>(src, s, K, k_prune, mask);
+    }
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+extern "C" int slim_mask_unstructured(const void* W_bf16, const float* s, int64_t N, int64_t K, int64_t k_prune,
+                                      uint8_t* mask, void* stream) {
+    return launch_unstructured(W_bf16, true, s, N, K, k_prune, mask, stream);
+}
+
+extern "C" int slim_prune_unstructured_f32(const float* metric, int64_t N, int64_t K, int64_t k_prune, uint8_t* mask,
+                                           void* stream) {
+    return launch_unstructured(metric, false, nullptr, N, K, k_prune, mask, stream);
+}

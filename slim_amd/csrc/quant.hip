@@ -445,7 +445,8 @@ extern "C" int slim_fake_quant_pt(const void* W, int64_t numel, const float* sf,
 __global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restrict__ w, const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ s, const float* __restrict__ sf_p,
                                                            int num_bits, int64_t N, int64_t K,
-                                                           float* __restrict__ e32, bf16_t* __restrict__ e16) {
+                                                           float* __restrict__ e32, bf16_t* __restrict__ e16,
+                                                           const bf16_t* __restrict__ wdeq) {
     const float sf = sf_p ? sf_p[0] : 0.f;
     const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
     const int64_t cpr = K >> 3, total = N * cpr;
@@ -453,6 +454,8 @@ __global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restr
         const int64_t row = t / cpr, c0 = (t - row * cpr) << 3, off = row * K + c0;
         const u16x8 x = *(const u16x8*)(w + off);
         const uint2 mk = *(const uint2*)(mask + off);
+        u16x8 xd = x;
+        if (wdeq) xd = *(const u16x8*)(wdeq + off);
         float sv[8];
         if (s) {
             const f32x4 a = *(const f32x4*)(s + c0), b = *(const f32x4*)(s + c0 + 4);
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restr
             const bool pruned = ((j < 4 ? mk.x >> (8 * j) : mk.y >> (8 * (j - 4))) & 0xffu) != 0;
             float nw;
             if (pruned) nw = 0.f;
+            else if (wdeq) nw = bf16_to_f32(xd[j]) * sv[j];
             else if (sf_p) nw = (quant_code(x[j], sf, qmin, qmax) / sf) * sv[j];
             else nw = metric;
             e[j] = metric - nw;
@@ -499,7 +503,22 @@ extern "C" int slim_error_matrix(const void* W, const uint8_t* mask, const float
     int64_t blocks = ceil_div64(N * (K >> 3), 256);
     blocks = blocks > 8192 ? 8192 : blocks;
     error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K,
-                                                                          E_f32, (bf16_t*)E_bf16);
+                                                                          E_f32, (bf16_t*)E_bf16, nullptr);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// Same with the dequantised weight given as a tensor (any quantiser, e.g. the tiled group quantiser whose
+// dequantised values are bf16): E = W * s - mask0(Wdeq * s).
+extern "C" int slim_error_matrix_deq(const void* W, const void* Wdeq, const uint8_t* mask, const float* s, int64_t N,
+                                     int64_t K, float* E_f32, void* E_bf16, void* stream) {
+    SLIM_REQUIRE(W && Wdeq && mask && (E_f32 || E_bf16) && N > 0 && K > 0, "slim_error_matrix_deq: bad arguments");
+    SLIM_REQUIRE(K % 8 == 0, "slim_error_matrix_deq: K must be a multiple of 8");
+    SLIM_PROF("error_matrix", stream, (5.0 + (E_f32 ? 4.0 : 0.0) + (E_bf16 ? 2.0 : 0.0)) * N * K);
+    int64_t blocks = ceil_div64(N * (K >> 3), 256);
+    blocks = blocks > 8192 ? 8192 : blocks;
+    error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, nullptr, 4, N, K, E_f32,
+                                                                          (bf16_t*)E_bf16, (const bf16_t*)Wdeq);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }

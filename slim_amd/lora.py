@@ -204,10 +204,6 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
         raise NotImplementedError("prune_lora is not implemented")
     if not separate_lora:
         raise NotImplementedError("separate_lora=False is not implemented")
-    if quantizer is not None and not quantize_first:
-        raise NotImplementedError("quantize_first=False is not implemented")
-    if quantizer is not None and quantizer.block_quantization:
-        raise NotImplementedError("tiled weight quantisation inside add_lora is not implemented")
     W = module.weight.data
     if W.dtype != torch.bfloat16 or not W.is_cuda:
         raise RuntimeError("add_lora expects a bf16 weight on the GPU")
@@ -222,11 +218,20 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     use_slim = bool(slim_lora) and not has_zero                                 # lora.py:139
     c.s = ops.sqrt(activations.scaler_row) if use_slim else None
 
-    # first quantisation (scale search on W) and error matrix  (lora.py:146-156 / :158-169)
-    sf1 = None
-    if quantizer is not None:
-        sf1 = _weight_scale(c.W, quantizer).reshape(1)
-    _, c.E = ops.error_matrix(c.W, W_mask, c.s, sf1, c.bits, out=E_out)
+    # first quantisation and error matrix  (lora.py:146-156 / :158-169).  quantize_first=False quantises the
+    # masked weight instead: a pruned weight quantises to 0 either way, so only the scale differs.
+    Wq_src = c.W
+    if quantizer is not None and not quantize_first:
+        Wq_src = c.W.clone()
+        Wq_src[W_mask] = 0
+    if quantizer is not None and quantizer.block_quantization:
+        # tiled group quantiser (quantization.py:139-148): its dequantised values are a bf16 tensor
+        Wdeq = _tiled_fake_quant(Wq_src, quantizer)
+        c.E = ops.error_matrix_deq(c.W, Wdeq, W_mask, c.s, out=E_out)
+        del Wdeq
+    else:
+        sf1 = _weight_scale(Wq_src, quantizer).reshape(1) if quantizer is not None else None
+        _, c.E = ops.error_matrix(c.W, W_mask, c.s, sf1, c.bits, out=E_out)
     c.Et = ops.transpose(c.E, out=Et_out)
 
     rank = lora_rank((N, K), rank_ratio, lora_tile_size)
@@ -288,7 +293,9 @@ def add_lora_finish(c):
     module, quantizer, rank = c.module, c.quantizer, c.rank
     new_weight = ops.lowrank_residual(U, lora_left, c.W, c.W_mask)
     sf_out = None
-    if quantizer is not None:
+    if quantizer is not None and quantizer.block_quantization:
+        new_weight = _tiled_fake_quant(new_weight, quantizer)
+    elif quantizer is not None:
         sf2 = _weight_scale(new_weight, quantizer)
         new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), c.bits)
         sf_out = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
@@ -307,14 +314,24 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     """Fit low-rank adapters to the compression error of `module` and re-quantise the residual weight
     (lora.py:105-213).  Sets module.lora_left [K, r], module.lora_right [r, N] and module.weight.data.
 
-    Implemented: quantizer None or per-tensor (SLiM-Quant / abs-max), slim_lora on or off,
-    quantize_first=True, separate_lora=True.  Other flag combinations raise NotImplementedError.
+    Implemented: quantizer None, per-tensor (SLiM-Quant / abs-max) or tiled group abs-max, slim_lora on or off,
+    quantize_first either way, separate_lora=True.  Other flag combinations raise NotImplementedError.
     The driver runs the three phases separately so that same-shape layers share one batched fit.
     """
     c = add_lora_prepare(module, W_mask, rank_ratio, slim_lora, activations, quantizer, prune_lora, separate_lora,
                          lora_tile_size, quantize_first, scale_important_weights)
     add_lora_fit([c])
     add_lora_finish(c)
+
+
+def _tiled_fake_quant(W, quantizer):
+    """deq(quant(W)) under the tiled group quantiser (Quantizer.quantize_weight block branch + dequantize_absmax,
+    quantization.py:139-148, :203-217) without touching the quantizer's state: layers are compressed concurrently."""
+    assert W.shape[0] % quantizer.block_dim == 0 and W.shape[1] % quantizer.block_dim == 0, \
+        "Input matrix size is not divisible by block size"
+    if quantizer.slim_quant:
+        raise NotImplementedError("SLiM-Quant is not supported for block quantization")
+    return ops.group_fake_quant(W.contiguous(), quantizer.block_dim, quantizer.num_bits)
 
 
 def _weight_scale(W, quantizer):

@@ -120,6 +120,23 @@ def mask_nm(W, s, n, m):
     return mask
 
 
+def mask_unstructured(W, s, k_prune):
+    """Fused saliency |W| * s and per-row selection of the k_prune smallest (True = pruned, ties to the lower index)."""
+    W = _chk(W, BF16, "W")
+    s = _chk(s, torch.float32, "s")
+    assert s.numel() == W.shape[1]
+    mask = torch.empty(W.shape, dtype=torch.bool, device=W.device)
+    _lib.call("slim_mask_unstructured", _p(W), _p(s), W.shape[0], W.shape[1], int(k_prune), _p(mask), _stream())
+    return mask
+
+
+def prune_unstructured_f32(metric, k_prune):
+    metric = _chk(metric, torch.float32, "metric")
+    mask = torch.empty(metric.shape, dtype=torch.bool, device=metric.device)
+    _lib.call("slim_prune_unstructured_f32", _p(metric), metric.shape[0], metric.shape[1], int(k_prune), _p(mask), _stream())
+    return mask
+
+
 def prune_nm_f32(metric, n, m):
     metric = _chk(metric, torch.float32, "metric")
     mask = torch.empty(metric.shape, dtype=torch.bool, device=metric.device)
@@ -196,6 +213,17 @@ def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=N
     e16 = _out_or_new(out, (N, K), W.device, "error_matrix") if want_bf16 else None
     _lib.call("slim_error_matrix", _p(W), _p(mask), _p(s), _p(sf), num_bits, N, K, _p(e32), _p(e16), _stream())
     return e32, e16
+
+
+def error_matrix_deq(W, Wdeq, mask, s, out=None):
+    """E (bf16) = W * s - mask0(Wdeq * s) for a dequantised weight given as a tensor."""
+    W = _chk(W, BF16, "W")
+    Wdeq = _chk(Wdeq, BF16, "Wdeq")
+    mask = _chk(mask, torch.bool, "mask")
+    N, K = W.shape
+    e16 = _out_or_new(out, (N, K), W.device, "error_matrix_deq")
+    _lib.call("slim_error_matrix_deq", _p(W), _p(Wdeq), _p(mask), _p(s), N, K, None, _p(e16), _stream())
+    return e16
 
 
 def transpose(x, out=None):

@@ -17,8 +17,11 @@ class PackedLinear(torch.nn.Module):
     scaling_factor, and optionally lora_left [K, r], lora_right [r, N], lora_rank, lora_quantizer.
     """
 
-    def __init__(self, lin):
+    def __init__(self, lin=None):
         super().__init__()
+        self._ws = None
+        if lin is None:              # filled by from_tensors
+            return
         W = lin.weight.data
         if not W.is_cuda or W.dtype != torch.bfloat16:
             raise RuntimeError("PackedLinear needs a bf16 weight on the GPU (slim_amd has no CPU path)")
@@ -55,9 +58,25 @@ class PackedLinear(torch.nn.Module):
             self.ReffT = torch.zeros(self.out_features, r8, dtype=torch.bfloat16, device=W.device)
             self.ReffT[:, :r] = R.t()
             self.rank = r
-        self._ws = None
         for hook_id, hook in lin._forward_pre_hooks.items():      # input fake-quantisation hooks carry over
             self._forward_pre_hooks[hook_id] = hook
+
+    TENSORS = ("vals", "meta", "sf", "bias", "LeffT", "ReffT")
+
+    @classmethod
+    def from_tensors(cls, tensors, out_features, in_features, rank, a_div, device):
+        """Rebuild from the tensors `state()` returns (a checkpoint written by save_packed)."""
+        self = cls()
+        self.out_features, self.in_features, self.rank, self.a_div = int(out_features), int(in_features), int(rank), float(a_div)
+        for k in cls.TENSORS:
+            t = tensors.get(k)
+            setattr(self, k, None if t is None else t.to(device).contiguous())
+        if self.vals.numel() * 4 != self.out_features * self.in_features or self.meta.numel() * 8 != self.vals.numel() * 4:
+            raise ValueError("packed tensors do not match the recorded shape")
+        return self
+
+    def state(self):
+        return {k: getattr(self, k) for k in self.TENSORS if getattr(self, k) is not None}
 
     def packed_bytes(self):
         n = self.vals.numel() + self.meta.numel()
@@ -98,3 +117,53 @@ def pack_model(model):
             dense += lin.weight.numel() * 2
             packed += pl.packed_bytes()
     return dense, packed
+
+
+FORMAT = "slim_amd.packed24/1"
+
+
+def _packed_modules(model):
+    for i, layer in enumerate(get_layers_list(model)):
+        for name, mod in layer.named_modules():
+            if isinstance(mod, PackedLinear):
+                yield f"{i}.{name}", layer, name, mod
+
+
+def save_packed(model, path):
+    """Write every PackedLinear of `model` to one safetensors file: per layer `<block>.<name>.{vals,meta,sf,bias,
+    LeffT,ReffT}` plus the shapes, rank and activation divisor in the file's metadata.  The rest of the model
+    (embeddings, norms, head) is not touched -- save it the usual way."""
+    import json
+    from safetensors.torch import save_file
+    tensors, index = {}, {}
+    for key, _, _, mod in _packed_modules(model):
+        for k, t in mod.state().items():
+            tensors[f"{key}.{k}"] = t.detach().cpu().contiguous()
+        index[key] = dict(out_features=mod.out_features, in_features=mod.in_features, rank=mod.rank, a_div=mod.a_div)
+    if not index:
+        raise ValueError("the model holds no PackedLinear; call pack_model first")
+    save_file(tensors, path, metadata={"format": FORMAT, "layers": json.dumps(index)})
+    return index
+
+
+def load_packed(model, path, device="cuda"):
+    """Replace the linears named in a save_packed file by PackedLinear modules built from it (the model needs the
+    right architecture, not the right weights).  Returns the number of layers replaced."""
+    import json
+    from safetensors import safe_open
+    with safe_open(path, framework="pt", device="cpu") as f:
+        meta = f.metadata() or {}
+        if meta.get("format") != FORMAT:
+            raise ValueError(f"{path} is not a {FORMAT} file")
+        index = json.loads(meta["layers"])
+        names = set(f.keys())
+        layers = get_layers_list(model)
+        for key, info in index.items():
+            block, name = key.split(".", 1)
+            tensors = {k: f.get_tensor(f"{key}.{k}") for k in PackedLinear.TENSORS if f"{key}.{k}" in names}
+            parent = layers[int(block)]
+            parts = name.split(".")
+            for p in parts[:-1]:
+                parent = getattr(parent, p)
+            setattr(parent, parts[-1], PackedLinear.from_tensors(tensors, device=device, **info))
+    return len(index)

@@ -190,7 +190,7 @@ def _run_block(layer, src, dst, kwargs, batch):
             dst[j:j + batch] = out
 
 
-def compress_linears(items, dev, prune_n, prune_m, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
+def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
                      quantize_lora=False, pad_lora=False, lora_tile_size=256, separate_lora=True, quantize_first=True,
                      scale_important_weights=False, tiled_weight_quantization=False, callback=None, describe=None,
                      n_streams=None):
@@ -208,7 +208,11 @@ def compress_linears(items, dev, prune_n, prune_m, quantizer=None, lora_rank=0.,
             W_mask = lin.weight.mask.to(dev)
             del lin.weight.mask
             return W_mask
-        return ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), prune_n, prune_m)
+        if prune_n != 0:
+            return ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), prune_n, prune_m)
+        # unstructured (prune.py:275-279): per row the int(K * ratio) smallest saliencies, ties to the lower index
+        K = lin.weight.shape[1]
+        return ops.mask_unstructured(lin.weight.data.contiguous(), ops.sqrt(wrapped.scaler_row), int(K * sparsity_ratio))
 
     def produced(lin):
         return [lin.weight.data, getattr(lin, "scaling_factor", None)] + \
@@ -219,14 +223,18 @@ def compress_linears(items, dev, prune_n, prune_m, quantizer=None, lora_rank=0.,
             if describe:
                 describe(name)
             W_mask = mask_of(lin, wrapped)
-            # prune.py:330-357, quantize_first branch: quantise the dense weight, then zero the mask
-            if not quantize_first:
-                raise NotImplementedError("quantize_first=False is not implemented")
-            if quantizer is not None:
-                codes = quantizer.quantize_weight(lin.weight.data)
-                lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
-                lin.scaling_factor = quantizer.scaling_factor
-            lin.weight.data[W_mask] = 0
+            # prune.py:330-357: quantise the dense weight then zero the mask, or the other way round
+            def quantise():
+                if quantizer is not None:
+                    codes = quantizer.quantize_weight(lin.weight.data)
+                    lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
+                    lin.scaling_factor = None if tiled_weight_quantization else quantizer.scaling_factor
+            if quantize_first:
+                quantise()
+                lin.weight.data[W_mask] = 0
+            else:
+                lin.weight.data[W_mask] = 0
+                quantise()
             if callback is not None:
                 callback(name, lin, wrapped)
             return produced(lin)
@@ -336,10 +344,6 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                 separate_lora=True, nsamples=128, seed=0, calibration_dataset="c4", pad_lora=False,
                 quantize_first=True, scale_important_weights=False):
     """Wanda N:M pruning + weight quantisation + low-rank adapters, block by block (prune.py:148-372)."""
-    if prune_n == 0:
-        raise NotImplementedError("unstructured Wanda pruning is not implemented (only N:M with M = 4)")
-    if tiled_weight_quantization and quantize_weight:
-        raise NotImplementedError("tiled weight quantisation is not implemented in the Wanda driver")
     if scale_important_weights:
         raise NotImplementedError("scale_important_weights is not implemented")
     dev = _device()
@@ -398,7 +402,7 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)
         compress_linears(
             [(n, subset[n], wrapped_layers[n]) for j, n in enumerate(names) if owner[j] == rank], dev, prune_n, prune_m,
-            quantizer=quantizer,
+            sparsity_ratio=sparsity_ratio, quantizer=quantizer,
             lora_rank=lora_rank, slim_lora=slim_lora, prune_lora=prune_lora, quantize_lora=quantize_lora, pad_lora=pad_lora,
             lora_tile_size=lora_tile_size, separate_lora=separate_lora, quantize_first=quantize_first,
             scale_important_weights=scale_important_weights, tiled_weight_quantization=tiled_weight_quantization,

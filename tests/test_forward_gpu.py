@@ -155,3 +155,43 @@ def test_packed_forward_leading_dims_and_hooks(ops):
     assert torch.equal(y.reshape(14, 256), packed(x.reshape(14, 512)))
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.linear24_forward(x.reshape(14, 512).cpu(), packed.vals, packed.meta, packed.sf, 256)
+
+
+def test_packed_checkpoint_round_trip(ops, tmp_path):
+    """pack_model -> save_packed -> load_packed into a freshly initialised model of the same architecture:
+    identical tensors and identical logits."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from slim_amd.packed import PackedLinear, pack_model, save_packed, load_packed
+    from slim_amd.utils import get_layers_list, find_layers
+    cfg = LlamaConfig(vocab_size=128, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                      num_key_value_heads=2, max_position_embeddings=32)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(DEV).eval()
+    # give every block linear the compressed form (2:4 sparse 4-bit levels + adapters)
+    for layer in get_layers_list(model):
+        for name, lin in find_layers(layer).items():
+            N, K = lin.weight.shape
+            src = build_layer(N, K, 16, seed=N + K, bias=False)
+            lin.weight.data = src.weight.data
+            lin.scaling_factor, lin.lora_rank = src.scaling_factor, src.lora_rank
+            lin.lora_left, lin.lora_right = src.lora_left, src.lora_right
+    dense, packed = pack_model(model)
+    assert packed < dense and sum(isinstance(m, PackedLinear) for m in model.modules()) == 14
+    ids = torch.randint(0, 128, (2, 16), generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        ref = model(ids).logits
+    path = str(tmp_path / "packed.safetensors")
+    index = save_packed(model, path)
+    assert len(index) == 14
+    torch.manual_seed(1)
+    fresh = LlamaForCausalLM(cfg).to(torch.bfloat16).to(DEV).eval()
+    fresh.load_state_dict({k: v for k, v in model.state_dict().items()}, strict=False)   # embeddings, norms, head
+    assert load_packed(fresh, path, DEV) == 14
+    for (ka, a), (kb, b) in zip(sorted((k, m) for k, m in model.named_modules() if isinstance(m, PackedLinear)),
+                                sorted((k, m) for k, m in fresh.named_modules() if isinstance(m, PackedLinear))):
+        assert ka == kb and a.rank == b.rank and a.a_div == b.a_div
+        for t in PackedLinear.TENSORS:
+            ta, tb = getattr(a, t), getattr(b, t)
+            assert (ta is None and tb is None) or torch.equal(ta, tb)
+    with torch.no_grad():
+        assert torch.equal(fresh(ids).logits, ref)
