@@ -497,6 +497,191 @@ static void plan_splits(int tiles, int64_t M, int64_t N, int nk_main, int nk_ad,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// small-batch kernel (M <= 16): weights straight to registers
+// ---------------------------------------------------------------------------------------------
+// At M <= 16 the weight is streamed once and shared by nobody, so the round trip through LDS and the
+// barrier per K-step of the tiled kernel are pure overhead.  Here a wave owns 32 output rows (two MFMA
+// row blocks) and walks its slice of the reduction in blocks of 128 channels.  The weight is the A operand:
+// lane (n = lane & 15, q = lane >> 4) owns row n and takes, for every block, the 32-channel chunk
+// 128 * kb + 32 * q -- one packed unit (8 B of codes + 4 B of positions), read 128 B-contiguous by the 16
+// lanes of a q group -- which it expands in registers into the four 8-channel A fragments of four MFMAs.
+// The activations are the B operand: lane (m = lane & 15, q) reads x[m][128 * kb + 32 * q + 8 * o ..] for MFMA
+// o, i.e. the channel order inside a block is permuted the same way on both operands, which a dot product
+// does not notice.  C[n][m]: a lane ends with four consecutive output rows of one activation row.
+// Each workgroup (4 waves = 128 rows = one packed tile row) writes fp32 partial sums for its slice of the
+// reduction; linear24_reduce_kernel combines the slices of the main and the adapter product with the
+// rounding points of the reference.
+struct DecArgs {
+    const bf16_t* x;       // [M, Kd] activations (row stride ldx)
+    int64_t ldx;
+    int M, N, Kd;
+    float a_div;           // every activation element becomes bf16(x / a_div) on load when != 1
+    const uint8_t* vals;   // PACKED: tile-major codes / positions of W [N, Kd]
+    const uint8_t* meta;
+    const float* sf;
+    const bf16_t* Wd;      // !PACKED: dense bf16 [N, Kd], row stride ldw
+    int64_t ldw;
+    int kb_per_slice;      // blocks of 128 channels per reduction slice
+    float* slab;           // [slices][M][N]; this launch writes slices slice0 .. slice0 + gridDim.y - 1
+    int slice0;
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
+    __shared__ uint32_t pair_lut[256];
+    __shared__ uint2 sel_lut[16];
+    const int t = threadIdx.x;
+    if (PACKED) {
+        const float sf = *g.sf;
+        const int c0 = ((int)((uint32_t)t << 28)) >> 28, c1 = ((int)((uint32_t)t << 24)) >> 28;
+        pair_lut[t] = (uint32_t)f32_to_bf16((float)c0 / sf) | ((uint32_t)f32_to_bf16((float)c1 / sf) << 16);
+        if (t < 16) {
+            const int p0 = t & 3, p1 = t >> 2;
+            uint32_t sv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv[e] = (e == p0) ? 0x0100u : (e == p1) ? 0x0302u : 0x0c0cu;
+            sel_lut[t] = make_uint2(sv[0] | (sv[1] << 16), sv[2] | (sv[3] << 16));
+        }
+        __syncthreads();
+    }
+    const int lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, q = lane >> 4;
+    const int tn = blockIdx.x;
+    const int nkb = (g.Kd + 127) / 128;
+    const int kb0 = blockIdx.y * g.kb_per_slice;
+    const int kb1 = min(kb0 + g.kb_per_slice, nkb);
+    const int m_row = fr < g.M ? fr : g.M - 1;
+    const bf16_t* xrow = g.x + (int64_t)m_row * g.ldx;
+    const int chunks = (g.Kd + 31) / 32;                // Kd is a multiple of 8 (of 64 when packed)
+    const int64_t ktiles = g.Kd / 64;
+
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    struct Stage {              // operands of one block of 128 channels, as loaded
+        uint2 pv[2];
+        uint32_t pm[2];
+        u16x8 wd[2][4];
+        u16x8 xb[4];
+    };
+    auto load_block = [&](Stage& sg, int kb) {
+        const int chunk = 4 * kb + q;
+        const bool ok = chunk < chunks;
+        const int k = chunk * 32;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (k + 8 * o < g.Kd) sg.xb[o] = *(const u16x8*)(xrow + k + 8 * o);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sg.xb[o][j] = 0;
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int r_in_tile = wave * 32 + rb * 16 + fr;
+            if (PACKED) {
+                if (ok) {
+                    const int64_t unit = (((int64_t)tn * ktiles + (chunk >> 1)) * 2 + (chunk & 1)) * 128 + r_in_tile;
+                    sg.pv[rb] = *(const uint2*)(g.vals + unit * 8);
+                    sg.pm[rb] = *(const uint32_t*)(g.meta + unit * 4);
+                } else {
+                    sg.pv[rb] = make_uint2(0u, 0u);
+                    sg.pm[rb] = 0x44444444u;          // positions (0, 1) with zero codes
+                }
+            } else {
+                const bf16_t* wrow = g.Wd + ((int64_t)tn * 128 + r_in_tile) * g.ldw + k;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    if (k + 8 * o < g.Kd) sg.wd[rb][o] = *(const u16x8*)(wrow + 8 * o);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sg.wd[rb][o][j] = 0;
+                    }
+                }
+            }
+        }
+    };
+    auto compute_block = [&](const Stage& sg) {
+        bf16x8 bx[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            u16x8 v = sg.xb[o];
+            if (g.a_div != 1.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16(bf16_to_f32(v[j]) / g.a_div);
+            }
+            bx[o] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                bf16x8 a;
+                if (PACKED) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int grp = 2 * o + h;
+                        const uint32_t byte = ((grp < 4 ? sg.pv[rb].x : sg.pv[rb].y) >> (8 * (grp & 3))) & 0xffu;
+                        const uint32_t pair = pair_lut[byte];
+                        const uint2 sel = sel_lut[(sg.pm[rb] >> (4 * grp)) & 0xfu];
+                        w[2 * h] = __builtin_amdgcn_perm(pair, pair, sel.x);
+                        w[2 * h + 1] = __builtin_amdgcn_perm(pair, pair, sel.y);
+                    }
+                    const uint4 packed4 = make_uint4(w[0], w[1], w[2], w[3]);
+                    a = __builtin_bit_cast(bf16x8, packed4);
+                } else {
+                    a = __builtin_bit_cast(bf16x8, sg.wd[rb][o]);
+                }
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bx[o], acc[rb], 0, 0, 0);
+            }
+        }
+    };
+    // two register stages: the loads of the next block are in flight while the current one is expanded and multiplied
+    Stage s0, s1;
+    if (kb0 < kb1) load_block(s0, kb0);
+    for (int kb = kb0; kb < kb1; kb += 2) {
+        if (kb + 1 < kb1) load_block(s1, kb + 1);
+        compute_block(s0);
+        if (kb + 1 < kb1) {
+            if (kb + 2 < kb1) load_block(s0, kb + 2);
+            compute_block(s1);
+        }
+    }
+    // C[n][m]: lane holds m = fr, rows n = 4 * q + reg of each row block
+    if (fr < g.M) {
+        float* sl = g.slab + ((int64_t)(g.slice0 + blockIdx.y) * g.M + fr) * g.N + (int64_t)tn * 128 + wave * 32 + 4 * q;
+        *(f32x4*)(sl) = acc[0];
+        *(f32x4*)(sl + 16) = acc[1];
+    }
+}
+
+#define DECODE_MAX_M 16
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// slices of a decode launch: enough workgroups to fill the chip four times over, at least two blocks per
+// slice, slab traffic (8 B per slice and output) below half of the streamed weight bytes
+static int decode_slices(int64_t M, int64_t N, int64_t Kd, double bytes_per_weight) {
+    const int nkb = (int)((Kd + 127) / 128);
+    const int64_t tiles = N / 128;
+    int64_t want = (1024 + tiles - 1) / tiles;
+    const int64_t cap = (int64_t)((double)N * (double)Kd * bytes_per_weight / (16.0 * (double)M * (double)N));
+    if (want > cap) want = cap;
+    if (want > nkb / 2) want = nkb / 2;
+    if (want < 1) want = 1;
+    const int per = (int)((nkb + want - 1) / want);
+    return (nkb + per - 1) / per;
+}
+
+template <bool PACKED>
+static int launch_decode(DecArgs g, int slices, hipStream_t st) {
+    const int nkb = (g.Kd + 127) / 128;
+    g.kb_per_slice = (nkb + slices - 1) / slices;
+    dim3 grid((unsigned)(g.N / 128), (unsigned)slices);
+    linear24_decode_kernel<PACKED><<<grid, 256, 0, st>>>(g);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 static int run_linear24(FwdArgs g, void* workspace, int64_t workspace_bytes, hipStream_t st) {
     const int TBM = g.M <= 16 ? 16 : g.M <= 32 ? 32 : g.M <= 64 ? 64 : 128;
     const int tiles = (g.N / FBN) * ((g.M + TBM - 1) / TBM);
@@ -537,7 +722,6 @@ static int run_linear24(FwdArgs g, void* workspace, int64_t workspace_bytes, hip
     return SLIM_OK;
 }
 
-static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // Workspace: t [M, r128] bf16 (r128 = r rounded up to 128, the width of the tile grid of the first launch)
 // followed by the split-reduction slab, sized for the larger of the two launches.
@@ -546,6 +730,13 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
     const int64_t r128 = round_up(r, 128);
     const int64_t t_bytes = round_up(M * r128 * 2, 256);
     int64_t slab = 0;
+    if (M <= DECODE_MAX_M) {
+        const int64_t r8 = round_up(r, 8);
+        const int64_t s1 = r ? decode_slices(M, r128, K, 2.0) : 0;
+        const int64_t s2 = decode_slices(M, N, K, 0.375) + (r ? decode_slices(M, N, r8, 2.0) : 0);
+        const int64_t a = s1 * M * r128 * 4, b = s2 * M * N * 4;
+        return t_bytes + (a > b ? a : b);
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const int64_t n = pass ? N : r128;
         if (n == 0) continue;
@@ -581,6 +772,70 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
     char* ws = (char*)workspace;
     int64_t ws_left = workspace_bytes;
     bf16_t* t = nullptr;
+    if (M <= DECODE_MAX_M) {
+        // small batch: weights straight to registers, every product through fp32 slices + one combine
+        const int64_t t_bytes = round_up(M * r128 * 2, 256);
+        float* slab = (float*)(ws + (r > 0 ? t_bytes : 0));
+        if (r > 0) {
+            SLIM_REQUIRE(((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0,
+                         "slim_linear24_forward: adapter operands must be 16-byte aligned");
+            t = (bf16_t*)ws;
+            DecArgs d{};
+            d.x = (const bf16_t*)x;
+            d.ldx = ldx;
+            d.M = (int)M;
+            d.N = (int)r128;
+            d.Kd = (int)K;
+            d.a_div = a_div;
+            d.Wd = (const bf16_t*)LeffT;
+            d.ldw = K;
+            d.slab = slab;
+            d.slice0 = 0;
+            const int s1 = decode_slices(M, r128, K, 2.0);
+            int rc = launch_decode<false>(d, s1, st);
+            if (rc != SLIM_OK) return rc;
+            const int64_t n1 = M * r128;
+            linear24_reduce_kernel<<<(unsigned)ceil_div64(n1, 256), 256, 0, st>>>(slab, 0, s1, (int)M, (int)r128, nullptr, t, r128);
+            SLIM_LAUNCH_CHECK();
+        }
+        DecArgs d{};
+        d.x = (const bf16_t*)x;
+        d.ldx = ldx;
+        d.M = (int)M;
+        d.N = (int)N;
+        d.Kd = (int)K;
+        d.a_div = 1.f;
+        d.vals = (const uint8_t*)vals;
+        d.meta = (const uint8_t*)meta;
+        d.sf = sf;
+        d.slab = slab;
+        d.slice0 = 0;
+        const int sm = decode_slices(M, N, K, 0.375);
+        int rc = launch_decode<true>(d, sm, st);
+        if (rc != SLIM_OK) return rc;
+        int sa = 0;
+        if (r > 0) {
+            DecArgs a{};
+            a.x = t;
+            a.ldx = r128;
+            a.M = (int)M;
+            a.N = (int)N;
+            a.Kd = (int)r8;
+            a.a_div = a_div;
+            a.Wd = (const bf16_t*)ReffT;
+            a.ldw = r8;
+            a.slab = slab;
+            a.slice0 = sm;
+            sa = decode_slices(M, N, r8, 2.0);
+            rc = launch_decode<false>(a, sa, st);
+            if (rc != SLIM_OK) return rc;
+        }
+        const int64_t n2 = M * N;
+        linear24_reduce_kernel<<<(unsigned)ceil_div64(n2, 256), 256, 0, st>>>(slab, sm, sa, (int)M, (int)N, (const bf16_t*)bias,
+                                                                             (bf16_t*)y, ldy);
+        SLIM_LAUNCH_CHECK();
+        return SLIM_OK;
+    }
     if (r > 0) {
         SLIM_REQUIRE(((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0,
                      "slim_linear24_forward: adapter operands must be 16-byte aligned");

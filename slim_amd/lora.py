@@ -202,13 +202,11 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
         raise NotImplementedError("scale_important_weights is not implemented")
     if prune_lora:
         raise NotImplementedError("prune_lora is not implemented")
-    if not separate_lora:
-        raise NotImplementedError("separate_lora=False is not implemented")
     W = module.weight.data
     if W.dtype != torch.bfloat16 or not W.is_cuda:
         raise RuntimeError("add_lora expects a bf16 weight on the GPU")
     c = LoraContext()
-    c.module, c.quantizer, c.W_mask = module, quantizer, W_mask
+    c.module, c.quantizer, c.W_mask, c.separate = module, quantizer, W_mask, bool(separate_lora)
     c.W = W.contiguous()
     N, K = c.W.shape
     c.bits = quantizer.num_bits if quantizer is not None else 4
@@ -261,9 +259,11 @@ def add_lora_fit(ctxs, E_group=None, Et_group=None):
     if E_group is None or len(ctxs) == 1:
         for c in ctxs:
             c.touch()
-            c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s, c.outliers, c.spread)
+            # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row)
+            c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if c.separate else None, c.outliers, c.spread)
         return
     assert len({c.group_key() for c in ctxs}) == 1 and ctxs[0].outliers is None and E_group.shape[0] == len(ctxs)
+    assert all(c.separate for c in ctxs), "merged adapters are fitted one by one"
     for c in ctxs:
         c.touch()
     rank = ctxs[0].rank
@@ -291,7 +291,16 @@ def add_lora_finish(c):
     c.touch()
     U, lora_right, lora_left, fit_info = c.fit
     module, quantizer, rank = c.module, c.quantizer, c.rank
-    new_weight = ops.lowrank_residual(U, lora_left, c.W, c.W_mask)
+    low_rank_weight = None
+    if c.separate:
+        new_weight = ops.lowrank_residual(U, lora_left, c.W, c.W_mask)
+    else:
+        # lora.py:189,197,200-201: the product U S V^T in bf16, divided by bf16(sqrt(scaler_row)) column-wise
+        _, low_rank_weight, _ = ops.gemm_nt(U, lora_left, out_bf16=True)
+        if c.s is not None:
+            low_rank_weight /= c.s.reshape(1, -1).to(torch.bfloat16)
+        new_weight = c.W - low_rank_weight
+        new_weight[c.W_mask] = 0
     sf_out = None
     if quantizer is not None and quantizer.block_quantization:
         new_weight = _tiled_fake_quant(new_weight, quantizer)
@@ -300,12 +309,16 @@ def add_lora_finish(c):
         new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), c.bits)
         sf_out = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
         quantizer.scaling_factor = sf_out
+    module.lora_fit_info = fit_info
+    if not c.separate:
+        # lora.py:213: the adapters are folded back into the (then dense) weight
+        module.weight.data = (new_weight.float() + low_rank_weight.float()).to(torch.bfloat16).contiguous()
+        return sf_out
     if lora_left.shape[1] != rank:       # the factors are padded to a multiple of 8 columns
         lora_left, lora_right = lora_left[:, :rank], lora_right[:rank]
     module.lora_left = torch.nn.Parameter(lora_left).to(torch.bfloat16).contiguous()
     module.lora_right = torch.nn.Parameter(lora_right).to(torch.bfloat16).contiguous()
     module.weight.data = new_weight.to(torch.bfloat16).contiguous()
-    module.lora_fit_info = fit_info
     return sf_out
 
 
@@ -315,7 +328,8 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     (lora.py:105-213).  Sets module.lora_left [K, r], module.lora_right [r, N] and module.weight.data.
 
     Implemented: quantizer None, per-tensor (SLiM-Quant / abs-max) or tiled group abs-max, slim_lora on or off,
-    quantize_first either way, separate_lora=True.  Other flag combinations raise NotImplementedError.
+    quantize_first either way, adapters kept separate or merged back.  scale_important_weights and prune_lora
+    raise NotImplementedError.
     The driver runs the three phases separately so that same-shape layers share one batched fit.
     """
     c = add_lora_prepare(module, W_mask, rank_ratio, slim_lora, activations, quantizer, prune_lora, separate_lora,

@@ -252,7 +252,7 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
     slot, buffers = {}, {}
     for key, members in groups.items():
         (N, K), _, _, batchable = key
-        if BATCH_FITS and batchable and len(members) > 1:
+        if BATCH_FITS and separate_lora and batchable and len(members) > 1:
             buffers[key] = (torch.empty(len(members), N, K, dtype=torch.bfloat16, device=dev),
                             torch.empty(len(members), K, N, dtype=torch.bfloat16, device=dev))
             for b, idx in enumerate(members):
@@ -316,14 +316,14 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
     run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
 
 
-def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale):
+def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale, separate_lora=True):
     """Every rank receives the compressed form of the linears it does not own (weight, adapters, scale) and gives
     them the attributes and the hook the owner's copy has."""
     from .lora import lora_rank as rank_of
     for j, n in enumerate(names):
         lin = subset[n]
         N, K = lin.weight.shape
-        if lora_rank > 0.:
+        if lora_rank > 0. and separate_lora:
             r = min(rank_of((N, K), lora_rank, lora_tile_size if tiled_rank else None), min(N, K))
             mine = owner[j] == rank
             parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale)
@@ -411,7 +411,7 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
 
         if world > 1:
             _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
-                            quantizer is not None and not tiled_weight_quantization)
+                            quantizer is not None and not tiled_weight_quantization, separate_lora)
 
         progress_bar.set_description(f"Layer {i} - Evaluating Output")
         _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)

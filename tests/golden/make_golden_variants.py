@@ -5,6 +5,7 @@ g8_e2e_llama run through the reference's prune_and_quantize with
   g11_unstructured : sparsity_type="unstructured" (per-row stable sort, slim/prune.py:275-279), 4-bit SLiM-Quant,
                      adapters of rank 0.1, tile 128
   g11_nolora       : 2:4, 4-bit SLiM-Quant, lora_rank = 0 (quantise, then mask; slim/prune.py:330-357)
+  g11_merged       : 2:4, 4-bit SLiM-Quant, rank 0.1 adapters folded back into the weight (separate_lora=False)
   g11_tiled        : (with --tiled, TRITON_INTERPRET=1, slow) weight_tiled_quantization=True, tile 128
 Only data is written.  Run:  python tests/golden/make_golden_variants.py [--tiled]
 """
@@ -103,6 +104,8 @@ def main():
         return
     run("unstructured", bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5, sparsity_type="unstructured",
         quantize_weight=True, lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=128)
+    run("merged", bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5, sparsity_type="2:4",
+        quantize_weight=True, lora_rank=0.1, slim_lora=True, separate_lora=False)
     run("nolora", bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5, sparsity_type="2:4",
         quantize_weight=True, lora_rank=0.)
 

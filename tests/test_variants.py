@@ -189,3 +189,26 @@ def test_driver_variants_match_reference(ops, golden, variant):
     ppl = _fp32_ppl(model, g8["eval_ids"])
     print(variant, "fp32-loss ppl ours", ppl, "reference (cpu)", float(g["ppl_fp32loss"]))
     assert abs(ppl - float(g["ppl_fp32loss"])) <= 0.01 * float(g["ppl_fp32loss"])
+
+
+@pytest.mark.gpu
+def test_driver_merged_adapters_match_reference(ops, golden):
+    """separate_lora=False: the adapters are folded back into a dense weight (lora.py:213); compare the merged
+    weights' saliency-weighted distance to the original with the reference's."""
+    from slim_amd.utils import get_layers_list, find_layers
+    g = golden("g11_merged")
+    model, g8, orig, stats = _run_driver(golden, bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5,
+                                         sparsity_type="2:4", quantize_weight=True, lora_rank=0.1, slim_lora=True,
+                                         separate_lora=False)
+    for i, layer in enumerate(get_layers_list(model)):
+        for name, lin in find_layers(layer).items():
+            p = f"L{i}/{name}/"
+            assert not hasattr(lin, "lora_left") and len(lin._forward_hooks) == 0 and lin.scaling_factor.shape == (1, 1)
+            s = torch.sqrt(stats[(i, name)]).cpu().reshape(1, -1)
+            W0 = orig[f"model.layers.{i}.{name}.weight"].float()
+            eo = torch.norm((W0 - lin.weight.data.float().cpu()) * s).item()
+            er = torch.norm((W0 - g[p + "weight"].float()) * s).item()
+            print(p, "weighted-error excess", round(eo / er - 1, 5))
+            assert eo <= er * (1.02 if i == 0 else 1.03), (p, eo, er)
+    ppl = _fp32_ppl(model, g8["eval_ids"])
+    assert abs(ppl - float(g["ppl_fp32loss"])) <= 0.01 * float(g["ppl_fp32loss"])
