@@ -85,6 +85,30 @@ def cpu_baseline(seconds_budget=30.0):
                       f"full torch.svd, re-quantisation): {dt:.1f} s", "seconds": dt}
 
 
+# kernel symbol (as a profiler prints it) of each family the in-library timer reports
+FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0>", "gemm_nt_small": "gemm_nt_kernel<1>", "gemm_nt_apply": "gemm_nt_kernel<2>",
+                 "gemm_nt_sketch": "gemm_nt_kernel<3>", "gemm_nt_big": "gemm_nt_kernel<4>", "gemm_nt_residual": "gemm_nt_kernel<5>",
+                 "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
+                 "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel"}
+
+
+def measured_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed PMC measurement of this same command
+    (profiles/r1c_pmc_traffic.json, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1c_pmc_traffic.json")
+    sym = FAMILY_KERNEL.get(family)
+    if sym is None or not os.path.exists(path):
+        return None
+    try:
+        kernels = json.load(open(path))["kernels"]
+        k = kernels.get(sym) or next((v for name, v in kernels.items() if sym in name), None)
+        if not k:
+            return None
+        return (k.get("read_bytes_per_launch") or 0.0) + (k.get("write_bytes_per_launch") or 0.0)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,11 +223,11 @@ def main():
         if dom is not None:
             if dom["name"].startswith("gemm"):
                 roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": dom["tfs"], "peak": MFMA_BF16_PEAK_TF,
-                            "unit": "TFLOP/s", "frac": dom["tfs"] / MFMA_BF16_PEAK_TF, "traffic": None,
+                            "unit": "TFLOP/s", "frac": dom["tfs"] / MFMA_BF16_PEAK_TF, "traffic": measured_traffic(dom["name"]),
                             "avg_launch_us": dom["avg_us"], "launches": dom["count"]}
             else:
                 roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                            "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": measured_traffic(dom["name"]),
                             "avg_launch_us": dom["avg_us"], "launches": dom["count"]}
         out = {
             "metric": "weight GB/s compressed (bf16 in)", "value": value, "unit": "GB/s", "n_gpus": world,

@@ -21,7 +21,7 @@ from .quantization.quantization import Quantizer as AutoQuantizer, QuantizedMatm
 from .utils import get_layers_list, find_layers
 
 # samples per block forward during calibration (statistics are accumulated per sample regardless)
-CALIBRATION_BATCH = 1
+CALIBRATION_BATCH = int(os.environ.get("SLIM_CALIBRATION_BATCH", "8"))
 # leave compressed blocks on the accelerator instead of returning them to the CPU like the reference
 KEEP_ON_DEVICE = False
 # optional callable(i, name, module, wrapped) invoked after each linear is compressed (tests, tracing)

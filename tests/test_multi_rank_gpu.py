@@ -29,6 +29,7 @@ g = torch.Generator().manual_seed(1)
 calib = [(torch.randint(0, 256, (1, 32), generator=g), None) for _ in range(8)]
 P.get_loaders = lambda *a, **k: (calib, None)
 P.KEEP_ON_DEVICE = True
+P.CALIBRATION_BATCH = 1      # the same forward shapes in both runs: a batched GEMM may round differently per batch size
 P.prune_and_quantize(m, None, bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5, sparsity_type="2:4",
                      quantize_weight=True, nsamples=8, lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=128)
 out = {}

@@ -1,11 +1,13 @@
-"""Per-kernel HBM traffic from two rocprofv3 counter-collection runs of tools/pmc_probe.py (one with
---pmc FETCH_SIZE, one with --pmc WRITE_SIZE):  python tools/pmc_summarize.py <fetch.csv> <write.csv> <out.json>
+"""Per-kernel HBM traffic from two rocprofv3 counter-collection runs of the same single-threaded command (one
+with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE):
 
-FETCH_SIZE / WRITE_SIZE are reported in KiB... of 1024 bytes? -- the unit is calibrated, not assumed: the
-statistics kernel (colsumsq_kernel) streams exactly 2 * rows * K bytes with 16-byte loads, so the factor that maps
-its FETCH_SIZE to that byte count is applied to every kernel's reads (on gfx950 wide streaming reads are tallied
-at half their size); writes are taken at face value in the counter's unit of 1024 bytes... and checked the same
-way against the transpose kernel, which writes exactly what it reads."""
+    python tools/pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <calib bytes>
+
+The counters' unit is calibrated, not assumed: the statistics kernel (colsumsq_kernel) streams exactly 2 bytes per
+activation element with 16-byte loads, so <calib bytes> = the bytes it read over the whole run (bench.py, one step:
+128 * 2048 * 2 * sum of the 7 linears' input widths = 18 656 788 480) fixes the bytes per FETCH_SIZE unit for wide
+streaming reads (on gfx950 these are tallied at half their size, which the calibration absorbs).  WRITE_SIZE is
+taken in its documented unit of 1024 bytes.  Output: read / write bytes per launch for every kernel."""
 import csv
 import json
 import sys
@@ -18,7 +20,7 @@ def load(path, counter):
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            name = row["Kernel_Name"].split("(")[0]
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
             agg[name][0] += 1
             agg[name][1] += float(row["Counter_Value"])
     return agg
@@ -26,12 +28,10 @@ def load(path, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    # calibration: colsumsq_kernel reads 16 samples x 2048 rows x 4096 columns of bf16 per launch (probe shape)
+    known = float(sys.argv[4])
     cal_name = next(k for k in fetch if "colsumsq_kernel" in k)
-    known = 16 * 2048 * 4096 * 2
-    per_launch = fetch[cal_name][1] / fetch[cal_name][0]
-    read_unit = known / per_launch            # bytes per counter unit for wide streaming reads
-    out = {"calibration": {"kernel": cal_name, "known_bytes": known, "counter_per_launch": per_launch,
+    read_unit = known / fetch[cal_name][1]
+    out = {"calibration": {"kernel": cal_name, "known_bytes_total": known, "counter_total": fetch[cal_name][1],
                            "bytes_per_fetch_unit": read_unit, "bytes_per_write_unit": 1024.0}, "kernels": {}}
     for name in sorted(set(fetch) | set(write)):
         n = fetch.get(name, write.get(name))[0]
@@ -40,8 +40,8 @@ def main():
         out["kernels"][name] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out["kernels"].items():
-        print(f"{k[:60]:60s} n={v['launches']:5d} read {0 if v['read_bytes_per_launch'] is None else v['read_bytes_per_launch']/1e6:10.2f} MB  "
-              f"write {0 if v['write_bytes_per_launch'] is None else v['write_bytes_per_launch']/1e6:10.2f} MB")
+        rd, wr = v["read_bytes_per_launch"] or 0.0, v["write_bytes_per_launch"] or 0.0
+        print(f"{k[:70]:70s} n={v['launches']:5d} read {rd / 1e6:10.2f} MB  write {wr / 1e6:10.2f} MB")
     print("calibration:", out["calibration"])
 
 
