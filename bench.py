@@ -153,13 +153,18 @@ def main():
 
     from slim_amd import ops
     from slim_amd.prune import compress_linears, block_stats
+    from slim_amd.layerwrapper import shared_inputs
     from slim_amd.quantization.quantization import Quantizer
 
     def step():
         wrapped = {}
-        for i in mine:                      # statistics pass (in the driver: hooks of the block forward)
-            lins[i].weight.data = W0[i]
-            wrapped[i] = collect_stats(lins[i], acts[LLAMA2_7B_BLOCK[i][3]])
+        # statistics pass (in the driver: hooks of the block forward).  As in a decoder block, q/k/v and gate/up
+        # read the same activation tensor, whose column sums the hooks then compute once.
+        with shared_inputs():
+            for i in mine:
+                lins[i].weight.data = W0[i]
+                wrapped[i] = collect_stats(lins[i], acts[LLAMA2_7B_BLOCK[i][3]])
+        for i in mine:
             wrapped[i].scaler_row = ops.shift_zeros(wrapped[i].scaler_row)
         block_stats([wrapped[i] for i in mine])                                               # one host sync
         for i in mine:                      # a fresh module state per step (hooks and adapters of the last step)

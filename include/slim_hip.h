@@ -248,6 +248,18 @@ int slim_linear24_forward(const void* x_bf16, int64_t ldx, int64_t M, int64_t K,
                           int64_t r, float a_div, void* y_bf16, int64_t ldy, void* workspace, int64_t workspace_bytes,
                           void* stream);
 
+/* The same for batches of at most 16 rows with the adapters kept in the 4-bit group-quantised form of
+ * slim.lora.quantize_lora (quantization/utils.py:123-128, :188-193: value = bf16(code / 7 * alpha), one bf16 scale per
+ * qblock consecutive reduction channels), which is what the reference's QuantizedMatmul recomputes from the
+ * dequantised tensors on every call (quantization.py:313-317):
+ *   qL_codes uint8 [r128, K / 2], qL_alpha bf16 [r128, K / qblock]  (L_eff^T, rows >= r zero),
+ *   qR_codes uint8 [N, r / 2],    qR_alpha bf16 [N, r / qblock]     (R_eff^T);  even channel in the low nibble;
+ *   r % qblock == 0, K % qblock == 0, qblock % 32 == 0.  Larger batches: -3 (use the dense-operand entry point). */
+int slim_linear24_forward_q4(const void* x_bf16, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta,
+                             const float* sf, int64_t N, const void* bias_bf16, const void* qL_codes, const void* qL_alpha,
+                             const void* qR_codes, const void* qR_alpha, int64_t r, int qblock, float a_div, void* y_bf16,
+                             int64_t ldy, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

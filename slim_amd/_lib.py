@@ -63,6 +63,7 @@ PROTOTYPES = {
     "slim_pack24_int4": (i32, [vp, vp, i64, i64, vp, vp, vp, vp]),
     "slim_unpack24_int4": (i32, [vp, vp, vp, i64, i64, vp, vp]),
     "slim_linear24_workspace_bytes": (i64, [i64, i64, i64, i64]),
+    "slim_linear24_forward_q4": (i32, [vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, f32, vp, i64, vp, i64, vp]),
     "slim_linear24_forward": (i32, [vp, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i64, f32, vp, i64, vp, i64, vp]),
 }
 

@@ -520,18 +520,28 @@ struct DecArgs {
     const uint8_t* vals;   // PACKED: tile-major codes / positions of W [N, Kd]
     const uint8_t* meta;
     const float* sf;
-    const bf16_t* Wd;      // !PACKED: dense bf16 [N, Kd], row stride ldw
+    const bf16_t* Wd;      // MODE_DENSE: dense bf16 [N, Kd], row stride ldw
     int64_t ldw;
+    const uint8_t* qcodes; // MODE_Q4: 4-bit codes [N, Kd / 2] (even channel in the low nibble) ...
+    const bf16_t* qalpha;  // ... and group scales [N, Kd / qblock]; value = bf16(code / 7 * alpha)
+    int qblock;
     int kb_per_slice;      // blocks of 128 channels per reduction slice
     float* slab;           // [slices][M][N]; this launch writes slices slice0 .. slice0 + gridDim.y - 1
     int slice0;
 };
 
-template <bool PACKED>
+enum { MODE_DENSE = 0, MODE_PACKED24 = 1, MODE_Q4 = 2 };
+template <int MODE>
 __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
+    constexpr bool PACKED = MODE == MODE_PACKED24;
     __shared__ uint32_t pair_lut[256];
     __shared__ uint2 sel_lut[16];
+    __shared__ float q4_level[16];     // code / 7 for the sixteen 4-bit codes (index = code & 15)
     const int t = threadIdx.x;
+    if (MODE == MODE_Q4) {
+        if (t < 16) q4_level[t] = (float)((int)((uint32_t)t << 28) >> 28) / 7.0f;
+        __syncthreads();
+    }
     if (PACKED) {
         const float sf = *g.sf;
         const int c0 = ((int)((uint32_t)t << 28)) >> 28, c1 = ((int)((uint32_t)t << 24)) >> 28;
@@ -562,6 +572,8 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
         uint32_t pm[2];
         u16x8 wd[2][4];
         u16x8 xb[4];
+        uint4 qc[2];            // MODE_Q4: 32 codes of the lane's chunk
+        float qa[2];            //          and their group scale
     };
     auto load_block = [&](Stage& sg, int kb) {
         const int chunk = 4 * kb + q;
@@ -586,6 +598,15 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
                 } else {
                     sg.pv[rb] = make_uint2(0u, 0u);
                     sg.pm[rb] = 0x44444444u;          // positions (0, 1) with zero codes
+                }
+            } else if (MODE == MODE_Q4) {
+                const int64_t row = (int64_t)tn * 128 + r_in_tile;
+                if (ok) {
+                    sg.qc[rb] = *(const uint4*)(g.qcodes + row * (g.Kd / 2) + k / 2);
+                    sg.qa[rb] = bf16_to_f32(g.qalpha[row * (g.Kd / g.qblock) + k / g.qblock]);
+                } else {
+                    sg.qc[rb] = make_uint4(0u, 0u, 0u, 0u);
+                    sg.qa[rb] = 0.f;
                 }
             } else {
                 const bf16_t* wrow = g.Wd + ((int64_t)tn * 128 + r_in_tile) * g.ldw + k;
@@ -629,6 +650,12 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
                     }
                     const uint4 packed4 = make_uint4(w[0], w[1], w[2], w[3]);
                     a = __builtin_bit_cast(bf16x8, packed4);
+                } else if (MODE == MODE_Q4) {
+                    const uint32_t word = o == 0 ? sg.qc[rb].x : o == 1 ? sg.qc[rb].y : o == 2 ? sg.qc[rb].z : sg.qc[rb].w;
+                    u16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16(q4_level[(word >> (4 * j)) & 15u] * sg.qa[rb]);
+                    a = __builtin_bit_cast(bf16x8, v);
                 } else {
                     a = __builtin_bit_cast(bf16x8, sg.wd[rb][o]);
                 }
@@ -672,12 +699,12 @@ static int decode_slices(int64_t M, int64_t N, int64_t Kd, double bytes_per_weig
     return (nkb + per - 1) / per;
 }
 
-template <bool PACKED>
+template <int MODE>
 static int launch_decode(DecArgs g, int slices, hipStream_t st) {
     const int nkb = (g.Kd + 127) / 128;
     g.kb_per_slice = (nkb + slices - 1) / slices;
     dim3 grid((unsigned)(g.N / 128), (unsigned)slices);
-    linear24_decode_kernel<PACKED><<<grid, 256, 0, st>>>(g);
+    linear24_decode_kernel<MODE><<<grid, 256, 0, st>>>(g);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
@@ -725,6 +752,85 @@ static int run_linear24(FwdArgs g, void* workspace, int64_t workspace_bytes, hip
 
 // Workspace: t [M, r128] bf16 (r128 = r rounded up to 128, the width of the tile grid of the first launch)
 // followed by the split-reduction slab, sized for the larger of the two launches.
+// Small-batch forward.  The adapter operands are either dense bf16 (LeffT / ReffT) or 4-bit group-quantised
+// (qL_* / qR_*: codes [rows, Kd / 2] and scales [rows, Kd / qblock]), never both.
+static int decode_path(const void* x, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta, const float* sf,
+                       int64_t N, const void* bias, const void* LeffT, const void* ReffT, const void* qL_codes,
+                       const void* qL_alpha, const void* qR_codes, const void* qR_alpha, int qblock, int64_t r, float a_div,
+                       void* y, int64_t ldy, char* ws, hipStream_t st) {
+    const int64_t r8 = round_up(r, 8), r128 = round_up(r, 128);
+    const bool q4 = qL_codes != nullptr;
+    SLIM_REQUIRE(r == 0 || q4 || (LeffT && ReffT && ((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0),
+                 "slim_linear24_forward: adapter operands must be 16-byte aligned");
+    // every product goes through fp32 slices + one combine
+    const int64_t t_bytes = round_up(M * r128 * 2, 256);
+    float* slab = (float*)(ws + (r > 0 ? t_bytes : 0));
+    bf16_t* t = nullptr;
+    if (r > 0) {
+        t = (bf16_t*)ws;
+        DecArgs d{};
+        d.x = (const bf16_t*)x;
+        d.ldx = ldx;
+        d.M = (int)M;
+        d.N = (int)r128;
+        d.Kd = (int)K;
+        d.a_div = a_div;
+        d.Wd = (const bf16_t*)LeffT;
+        d.ldw = K;
+        d.qcodes = (const uint8_t*)qL_codes;
+        d.qalpha = (const bf16_t*)qL_alpha;
+        d.qblock = qblock;
+        d.slab = slab;
+        d.slice0 = 0;
+        const int s1 = decode_slices(M, r128, K, q4 ? 0.5 : 2.0);
+        const int rc = q4 ? launch_decode<MODE_Q4>(d, s1, st) : launch_decode<MODE_DENSE>(d, s1, st);
+        if (rc != SLIM_OK) return rc;
+        const int64_t n1 = M * r128;
+        linear24_reduce_kernel<<<(unsigned)ceil_div64(n1, 256), 256, 0, st>>>(slab, 0, s1, (int)M, (int)r128, nullptr, t, r128);
+        SLIM_LAUNCH_CHECK();
+    }
+    DecArgs d{};
+    d.x = (const bf16_t*)x;
+    d.ldx = ldx;
+    d.M = (int)M;
+    d.N = (int)N;
+    d.Kd = (int)K;
+    d.a_div = 1.f;
+    d.vals = (const uint8_t*)vals;
+    d.meta = (const uint8_t*)meta;
+    d.sf = sf;
+    d.slab = slab;
+    d.slice0 = 0;
+    const int sm = decode_slices(M, N, K, 0.375);
+    int rc = launch_decode<MODE_PACKED24>(d, sm, st);
+    if (rc != SLIM_OK) return rc;
+    int sa = 0;
+    if (r > 0) {
+        DecArgs a{};
+        a.x = t;
+        a.ldx = r128;
+        a.M = (int)M;
+        a.N = (int)N;
+        a.Kd = (int)r8;
+        a.a_div = a_div;
+        a.Wd = (const bf16_t*)ReffT;
+        a.ldw = r8;
+        a.qcodes = (const uint8_t*)qR_codes;
+        a.qalpha = (const bf16_t*)qR_alpha;
+        a.qblock = qblock;
+        a.slab = slab;
+        a.slice0 = sm;
+        sa = decode_slices(M, N, r8, q4 ? 0.5 : 2.0);
+        rc = q4 ? launch_decode<MODE_Q4>(a, sa, st) : launch_decode<MODE_DENSE>(a, sa, st);
+        if (rc != SLIM_OK) return rc;
+    }
+    const int64_t n2 = M * N;
+    linear24_reduce_kernel<<<(unsigned)ceil_div64(n2, 256), 256, 0, st>>>(slab, sm, sa, (int)M, (int)N, (const bf16_t*)bias,
+                                                                         (bf16_t*)y, ldy);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r) {
     if (M <= 0 || N <= 0 || K <= 0 || r < 0) return -1;
     const int64_t r128 = round_up(r, 128);
@@ -732,8 +838,9 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
     int64_t slab = 0;
     if (M <= DECODE_MAX_M) {
         const int64_t r8 = round_up(r, 8);
-        const int64_t s1 = r ? decode_slices(M, r128, K, 2.0) : 0;
-        const int64_t s2 = decode_slices(M, N, K, 0.375) + (r ? decode_slices(M, N, r8, 2.0) : 0);
+        const int64_t s1 = r ? max(decode_slices(M, r128, K, 2.0), decode_slices(M, r128, K, 0.5)) : 0;
+        const int64_t s2 = decode_slices(M, N, K, 0.375) +
+                           (r ? max(decode_slices(M, N, r8, 2.0), decode_slices(M, N, r8, 0.5)) : 0);
         const int64_t a = s1 * M * r128 * 4, b = s2 * M * N * 4;
         return t_bytes + (a > b ? a : b);
     }
@@ -772,70 +879,9 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
     char* ws = (char*)workspace;
     int64_t ws_left = workspace_bytes;
     bf16_t* t = nullptr;
-    if (M <= DECODE_MAX_M) {
-        // small batch: weights straight to registers, every product through fp32 slices + one combine
-        const int64_t t_bytes = round_up(M * r128 * 2, 256);
-        float* slab = (float*)(ws + (r > 0 ? t_bytes : 0));
-        if (r > 0) {
-            SLIM_REQUIRE(((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0,
-                         "slim_linear24_forward: adapter operands must be 16-byte aligned");
-            t = (bf16_t*)ws;
-            DecArgs d{};
-            d.x = (const bf16_t*)x;
-            d.ldx = ldx;
-            d.M = (int)M;
-            d.N = (int)r128;
-            d.Kd = (int)K;
-            d.a_div = a_div;
-            d.Wd = (const bf16_t*)LeffT;
-            d.ldw = K;
-            d.slab = slab;
-            d.slice0 = 0;
-            const int s1 = decode_slices(M, r128, K, 2.0);
-            int rc = launch_decode<false>(d, s1, st);
-            if (rc != SLIM_OK) return rc;
-            const int64_t n1 = M * r128;
-            linear24_reduce_kernel<<<(unsigned)ceil_div64(n1, 256), 256, 0, st>>>(slab, 0, s1, (int)M, (int)r128, nullptr, t, r128);
-            SLIM_LAUNCH_CHECK();
-        }
-        DecArgs d{};
-        d.x = (const bf16_t*)x;
-        d.ldx = ldx;
-        d.M = (int)M;
-        d.N = (int)N;
-        d.Kd = (int)K;
-        d.a_div = 1.f;
-        d.vals = (const uint8_t*)vals;
-        d.meta = (const uint8_t*)meta;
-        d.sf = sf;
-        d.slab = slab;
-        d.slice0 = 0;
-        const int sm = decode_slices(M, N, K, 0.375);
-        int rc = launch_decode<true>(d, sm, st);
-        if (rc != SLIM_OK) return rc;
-        int sa = 0;
-        if (r > 0) {
-            DecArgs a{};
-            a.x = t;
-            a.ldx = r128;
-            a.M = (int)M;
-            a.N = (int)N;
-            a.Kd = (int)r8;
-            a.a_div = a_div;
-            a.Wd = (const bf16_t*)ReffT;
-            a.ldw = r8;
-            a.slab = slab;
-            a.slice0 = sm;
-            sa = decode_slices(M, N, r8, 2.0);
-            rc = launch_decode<false>(a, sa, st);
-            if (rc != SLIM_OK) return rc;
-        }
-        const int64_t n2 = M * N;
-        linear24_reduce_kernel<<<(unsigned)ceil_div64(n2, 256), 256, 0, st>>>(slab, sm, sa, (int)M, (int)N, (const bf16_t*)bias,
-                                                                             (bf16_t*)y, ldy);
-        SLIM_LAUNCH_CHECK();
-        return SLIM_OK;
-    }
+    if (M <= DECODE_MAX_M)
+        return decode_path(x, ldx, M, K, vals, meta, sf, N, bias, LeffT, ReffT, nullptr, nullptr, nullptr, nullptr, 0, r, a_div,
+                           y, ldy, ws, st);
     if (r > 0) {
         SLIM_REQUIRE(((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0,
                      "slim_linear24_forward: adapter operands must be 16-byte aligned");
@@ -881,4 +927,39 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
     g.y = (bf16_t*)y;
     g.ldy = ldy;
     return run_linear24(g, ws, ws_left, st);
+}
+
+// Small-batch forward (M <= 16) with the adapters in 4-bit group-quantised form, as slim.lora.quantize_lora
+// defines it (quantization/utils.py:123-128, :188-193): value = bf16(code / 7 * alpha), one bf16 scale per
+// `qblock` consecutive reduction channels.  Operands are laid out for the kernel:
+//   qL_codes uint8 [r128, K / 2], qL_alpha bf16 [r128, K / qblock]   (L_eff^T, rows >= r zero)
+//   qR_codes uint8 [N, r / 2],    qR_alpha bf16 [N, r / qblock]      (R_eff^T), r % qblock == 0, qblock % 32 == 0
+// with the even channel of a byte in its low nibble.  Everything else as slim_linear24_forward.
+extern "C" int slim_linear24_forward_q4(const void* x, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta,
+                                        const float* sf, int64_t N, const void* bias, const void* qL_codes,
+                                        const void* qL_alpha, const void* qR_codes, const void* qR_alpha, int64_t r,
+                                        int qblock, float a_div, void* y, int64_t ldy, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(x && vals && meta && sf && y && qL_codes && qL_alpha && qR_codes && qR_alpha, "slim_linear24_forward_q4: null pointer");
+    if (M > DECODE_MAX_M) {
+        slim_set_error("slim_linear24_forward_q4: batches above %d rows take dense adapter operands (slim_linear24_forward)", DECODE_MAX_M);
+        return SLIM_ERR_UNSUPPORTED;
+    }
+    SLIM_REQUIRE(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 64 == 0 && N < (1 << 30) && K < (1 << 30),
+                 "slim_linear24_forward_q4: N must be a multiple of 128 and K of 64");
+    SLIM_REQUIRE(ldx >= K && ldx % 8 == 0 && ldy >= N && ((uintptr_t)x % 16) == 0,
+                 "slim_linear24_forward_q4: x must be 16-byte aligned with a row stride that is a multiple of 8");
+    SLIM_REQUIRE(r > 0 && qblock >= 32 && qblock % 32 == 0 && r % qblock == 0 && K % qblock == 0,
+                 "slim_linear24_forward_q4: r and K must be multiples of qblock, qblock of 32");
+    SLIM_REQUIRE(((uintptr_t)qL_codes % 16) == 0 && ((uintptr_t)qR_codes % 16) == 0,
+                 "slim_linear24_forward_q4: code arrays must be 16-byte aligned");
+    SLIM_REQUIRE(a_div > 0.f, "slim_linear24_forward_q4: a_div must be positive");
+    SLIM_REQUIRE(workspace && workspace_bytes >= slim_linear24_workspace_bytes(M, N, K, r) && ((uintptr_t)workspace % 256) == 0,
+                 "slim_linear24_forward_q4: workspace too small or not 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    SLIM_PROF("linear24_small_batch_q4", st,
+              (double)N * K * 0.375 + (double)(K + N) * r * (0.5 + 2.0 / qblock) + (double)M * (K + N) * 2.0,
+              2.0 * M * ((double)N * K + (double)(K + N) * r));
+    return decode_path(x, ldx, M, K, vals, meta, sf, N, bias, nullptr, nullptr, qL_codes, qL_alpha, qR_codes, qR_alpha, qblock, r,
+                       a_div, y, ldy, (char*)workspace, st);
 }

@@ -5,6 +5,36 @@ import torch.nn as nn
 from . import ops
 
 
+import contextlib
+
+# Linears fed by the same tensor (q/k/v, gate/up of a decoder block) need its column sums once.  Inside a
+# `shared_inputs()` scope -- the driver opens one around each block forward -- the sums are cached by the
+# identity of the input tensor; the cache keeps the tensor alive, so its address cannot be reused by another
+# tensor while the entry exists, and dies with the scope.
+_shared = None
+
+
+@contextlib.contextmanager
+def shared_inputs():
+    global _shared
+    outer, _shared = _shared, {}
+    try:
+        yield
+    finally:
+        _shared = outer
+
+
+def _sample_sums(flat, b):
+    if _shared is None:
+        return ops.colsumsq(flat, n_chunks=b)
+    key = (flat.data_ptr(), tuple(flat.shape), flat._version, b)
+    hit = _shared.get(key)
+    if hit is None:
+        hit = (flat, ops.colsumsq(flat, n_chunks=b))
+        _shared[key] = hit
+    return hit[1]
+
+
 class WrappedGPT:
     """Running per-input-column activation statistic of one nn.Linear.
 
@@ -53,7 +83,11 @@ class WrappedGPT:
         if self.defer:
             if not per_sample:
                 raise ValueError("deferred statistics are kept per sample")
-            self.sample_sums.append(ops.colsumsq(flat, n_chunks=b))
+            self.sample_sums.append(_sample_sums(flat, b))
+        elif per_sample and _shared is not None:
+            # column sums (possibly shared with the other linears reading this tensor) + the recurrence:
+            # the same arithmetic, in the same order, as the fused call below
+            ops.scaler_row_fold(self.scaler_row, _sample_sums(flat, b), self.nsamples, batch_per_chunk=1)
         elif per_sample:
             ops.scaler_row_accum(flat, self.scaler_row, self.nsamples, n_chunks=b, batch_per_chunk=1)
         else:

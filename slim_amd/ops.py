@@ -378,13 +378,18 @@ def group_dequantize(codes, alphas, bits):
     return out
 
 
-def group_fake_quant(x, block, bits, want_alphas=False):
+def group_fake_quant(x, block, bits, want_alphas=False, want_codes=False):
+    """deq(quant(x)) with one scale per (block rows x 1 column); optionally also the scales bf16 [M / block, N]
+    and the int8 codes [M, N].  Returns out | (out, alphas) | (out, alphas, codes)."""
     x = _chk(x, BF16, "x")
     M, N = x.shape
     assert M % block == 0 and N % block == 0, "Input matrix size is not divisible by block size"
     out = torch.empty_like(x)
-    al = torch.empty(M // block, N, dtype=BF16, device=x.device) if want_alphas else None
-    _lib.call("slim_group_fake_quant", _p(x), M, N, block, bits, _p(out), _p(al), None, _stream())
+    al = torch.empty(M // block, N, dtype=BF16, device=x.device) if (want_alphas or want_codes) else None
+    codes = torch.empty(M, N, dtype=torch.int8, device=x.device) if want_codes else None
+    _lib.call("slim_group_fake_quant", _p(x), M, N, block, bits, _p(out), _p(al), _p(codes), _stream())
+    if want_codes:
+        return out, al, codes
     return (out, al) if want_alphas else out
 
 
@@ -466,4 +471,34 @@ def linear24_forward(x, vals, meta, sf, N, bias=None, LeffT=None, ReffT=None, r=
     y = torch.empty(M, N, dtype=BF16, device=x.device)
     _lib.call("slim_linear24_forward", _p(x), K, M, K, _p(vals), _p(meta), _p(sf), N, _p(bias), _p(LeffT), _p(ReffT), r,
               float(a_div), _p(y), N, _p(ws), ws.numel(), _stream())
+    return y
+
+
+def pack_q4_operand(codes_t, alphas_t, rows_pad=None):
+    """Kernel layout of a 4-bit group-quantised operand: codes_t int8 [rows, Kd] (reduction dimension last) ->
+    uint8 [rows_pad, Kd / 2] with the even channel in the low nibble; alphas_t bf16 [rows, Kd / block] ->
+    [rows_pad, Kd / block].  Rows beyond `rows` are zero."""
+    rows, Kd = codes_t.shape
+    rows_pad = rows if rows_pad is None else rows_pad
+    c = codes_t.to(torch.int16) & 15
+    packed = (c[:, 0::2] | (c[:, 1::2] << 4)).to(torch.uint8)
+    qc = torch.zeros(rows_pad, Kd // 2, dtype=torch.uint8, device=codes_t.device)
+    qc[:rows] = packed
+    qa = torch.zeros(rows_pad, alphas_t.shape[1], dtype=BF16, device=codes_t.device)
+    qa[:rows] = alphas_t
+    return qc.contiguous(), qa.contiguous()
+
+
+def linear24_forward_q4(x, vals, meta, sf, N, bias, qL, qR, r, qblock, a_div, ws=None):
+    """Small-batch (M <= 16) forward with 4-bit group-quantised adapters; qL / qR = (codes, alphas) from pack_q4_operand."""
+    x = _chk(x, BF16, "x")
+    M, K = x.shape
+    if bias is not None:
+        bias = _chk(bias, BF16, "bias")
+    need = _lib.query("slim_linear24_workspace_bytes", M, N, K, r)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, x.device)
+    y = torch.empty(M, N, dtype=BF16, device=x.device)
+    _lib.call("slim_linear24_forward_q4", _p(x), K, M, K, _p(vals), _p(meta), _p(sf), N, _p(bias), _p(qL[0]), _p(qL[1]),
+              _p(qR[0]), _p(qR[1]), r, int(qblock), float(a_div), _p(y), N, _p(ws), ws.numel(), _stream())
     return y

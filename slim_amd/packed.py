@@ -35,6 +35,8 @@ class PackedLinear(torch.nn.Module):
         self.rank = 0
         self.a_div = 1.0
         self.LeffT = self.ReffT = None
+        self.qL = self.qR = None       # 4-bit adapter operands of the small-batch path
+        self.qblock = 0
         if hasattr(lin, "lora_left"):
             r = int(lin.lora_rank)
             sqrt_r = torch.sqrt(lin.lora_rank)        # on the device the reference computes it on (lora_rank's own)
@@ -45,9 +47,14 @@ class PackedLinear(torch.nn.Module):
                 # and the hook divides the activations by sqrt(rank) (prune.py:305-312)
                 if not q.block_quantization:
                     raise NotImplementedError("PackedLinear supports group-quantised adapters only")
-                L = ops.group_fake_quant(L.contiguous(), q.block_dim, q.num_bits)
-                R = ops.group_fake_quant(R.contiguous(), q.block_dim, q.num_bits)
+                L, aL, cL = ops.group_fake_quant(L.contiguous(), q.block_dim, q.num_bits, want_codes=True)
+                R, aR, cR = ops.group_fake_quant(R.contiguous(), q.block_dim, q.num_bits, want_codes=True)
                 self.a_div = float(sqrt_r)
+                if q.num_bits == 4 and q.block_dim % 32 == 0:
+                    # codes and scales themselves, laid out for the small-batch kernel (0.5 byte per element)
+                    self.qblock = int(q.block_dim)
+                    self.qL = ops.pack_q4_operand(cL.t().contiguous(), aL.t().contiguous(), -(-r // 128) * 128)
+                    self.qR = ops.pack_q4_operand(cR.t().contiguous(), aR.t().contiguous())
             else:
                 # prune.py:317-321 divides the adapters by sqrt(rank) on every call
                 sqrt_r = sqrt_r if sqrt_r.dim() == 0 and not sqrt_r.is_cuda else sqrt_r.to(W.device)
@@ -61,26 +68,35 @@ class PackedLinear(torch.nn.Module):
         for hook_id, hook in lin._forward_pre_hooks.items():      # input fake-quantisation hooks carry over
             self._forward_pre_hooks[hook_id] = hook
 
-    TENSORS = ("vals", "meta", "sf", "bias", "LeffT", "ReffT")
+    TENSORS = ("vals", "meta", "sf", "bias", "LeffT", "ReffT", "qL_codes", "qL_alpha", "qR_codes", "qR_alpha")
 
     @classmethod
-    def from_tensors(cls, tensors, out_features, in_features, rank, a_div, device):
+    def from_tensors(cls, tensors, out_features, in_features, rank, a_div, device, qblock=0):
         """Rebuild from the tensors `state()` returns (a checkpoint written by save_packed)."""
         self = cls()
         self.out_features, self.in_features, self.rank, self.a_div = int(out_features), int(in_features), int(rank), float(a_div)
-        for k in cls.TENSORS:
-            t = tensors.get(k)
-            setattr(self, k, None if t is None else t.to(device).contiguous())
+        self.qblock = int(qblock)
+        got = {k: (None if tensors.get(k) is None else tensors[k].to(device).contiguous()) for k in cls.TENSORS}
+        for k in ("vals", "meta", "sf", "bias", "LeffT", "ReffT"):
+            setattr(self, k, got[k])
+        self.qL = (got["qL_codes"], got["qL_alpha"]) if got["qL_codes"] is not None else None
+        self.qR = (got["qR_codes"], got["qR_alpha"]) if got["qR_codes"] is not None else None
         if self.vals.numel() * 4 != self.out_features * self.in_features or self.meta.numel() * 8 != self.vals.numel() * 4:
             raise ValueError("packed tensors do not match the recorded shape")
         return self
 
     def state(self):
-        return {k: getattr(self, k) for k in self.TENSORS if getattr(self, k) is not None}
+        out = {k: getattr(self, k) for k in ("vals", "meta", "sf", "bias", "LeffT", "ReffT") if getattr(self, k) is not None}
+        if self.qL is not None:
+            out.update(qL_codes=self.qL[0], qL_alpha=self.qL[1], qR_codes=self.qR[0], qR_alpha=self.qR[1])
+        return out
 
     def packed_bytes(self):
+        """Bytes the small-batch forward streams: packed weight + adapters (4-bit when quantised, else bf16)."""
         n = self.vals.numel() + self.meta.numel()
-        if self.rank:
+        if self.qL is not None:
+            n += sum(t.numel() * t.element_size() for t in self.qL + self.qR)
+        elif self.rank:
             n += 2 * (self.LeffT.numel() + self.ReffT.numel())
         return n
 
@@ -93,8 +109,12 @@ class PackedLinear(torch.nn.Module):
         x2 = x.reshape(-1, shape[-1])
         if x2.dtype != torch.bfloat16:
             x2 = x2.to(torch.bfloat16)
-        y = ops.linear24_forward(x2.contiguous(), self.vals, self.meta, self.sf, self.out_features, self.bias,
-                                 self.LeffT, self.ReffT, self.rank, self.a_div)
+        if self.qL is not None and x2.shape[0] <= 16:
+            y = ops.linear24_forward_q4(x2.contiguous(), self.vals, self.meta, self.sf, self.out_features, self.bias,
+                                        self.qL, self.qR, self.rank, self.qblock, self.a_div)
+        else:
+            y = ops.linear24_forward(x2.contiguous(), self.vals, self.meta, self.sf, self.out_features, self.bias,
+                                     self.LeffT, self.ReffT, self.rank, self.a_div)
         return y.reshape(*shape[:-1], self.out_features)
 
     def extra_repr(self):
@@ -139,7 +159,8 @@ def save_packed(model, path):
     for key, _, _, mod in _packed_modules(model):
         for k, t in mod.state().items():
             tensors[f"{key}.{k}"] = t.detach().cpu().contiguous()
-        index[key] = dict(out_features=mod.out_features, in_features=mod.in_features, rank=mod.rank, a_div=mod.a_div)
+        index[key] = dict(out_features=mod.out_features, in_features=mod.in_features, rank=mod.rank, a_div=mod.a_div,
+                          qblock=mod.qblock)
     if not index:
         raise ValueError("the model holds no PackedLinear; call pack_model first")
     save_file(tensors, path, metadata={"format": FORMAT, "layers": json.dumps(index)})

@@ -15,7 +15,7 @@ import tqdm.auto as tqdm
 
 from . import ops, parallel
 from .data import get_loaders
-from .layerwrapper import WrappedGPT
+from .layerwrapper import WrappedGPT, shared_inputs
 from .lora import add_lora  # noqa: F401  (re-exported: slim.prune.add_lora in the reference)
 from .quantization.quantization import Quantizer as AutoQuantizer, QuantizedMatmul
 from .utils import get_layers_list, find_layers
@@ -184,7 +184,8 @@ def _run_block(layer, src, dst, kwargs, batch):
     n = src.shape[0]
     with torch.no_grad():
         for j in range(0, n, batch):
-            out = layer(src[j:j + batch], **kwargs)
+            with shared_inputs():       # q/k/v (gate/up) read one tensor: its column sums are computed once
+                out = layer(src[j:j + batch], **kwargs)
             if isinstance(out, (tuple, list)):      # older decoder layers return (hidden_states, ...)
                 out = out[0]
             dst[j:j + batch] = out

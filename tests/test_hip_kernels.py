@@ -426,3 +426,29 @@ def test_lowrank_fit_batched_matches_single(ops):
         # its arithmetic differently, so the pin is the reconstruction error
         assert abs(eb / es_ - 1) <= 1e-3
         torch.testing.assert_close(batched["S"][b].cpu()[: r // 2], single["S"].cpu()[: r // 2], rtol=1e-3, atol=0)
+
+
+def test_shared_input_statistics_are_bit_identical(ops):
+    """Column sums computed once for linears reading the same tensor + the separate recurrence call give exactly
+    the scaler_row of the fused per-linear call."""
+    from slim_amd.layerwrapper import WrappedGPT, shared_inputs
+    g = torch.Generator().manual_seed(5)
+    X = (torch.randn(6, 300, 512, generator=g) * torch.exp(torch.randn(512, generator=g))).to(torch.bfloat16).to(DEV)
+    lins = [torch.nn.Linear(512, 64, bias=False).to(torch.bfloat16).to(DEV) for _ in range(3)]
+    plain = WrappedGPT(lins[0])
+    plain.add_batch(X[:4], None, per_sample=True)
+    plain.add_batch(X[4:], None, per_sample=True)
+    shared = [WrappedGPT(l) for l in lins]
+    calls = []
+    real = ops.colsumsq
+    try:
+        ops.colsumsq = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        for part in (X[:4], X[4:]):
+            with shared_inputs():
+                for w in shared:
+                    w.add_batch(part, None, per_sample=True)
+    finally:
+        ops.colsumsq = real
+    assert len(calls) == 2                      # once per distinct input tensor, not once per linear
+    for w in shared:
+        assert w.nsamples == 6 and torch.equal(w.scaler_row, plain.scaler_row)

@@ -29,8 +29,9 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="truncate to this many decoder blocks (0 = all)")
     ap.add_argument("--nsamples", type=int, default=128)
     ap.add_argument("--seqlen", type=int, default=2048)
-    ap.add_argument("--calib-batch", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--calib-batch", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=7)
+    ap.add_argument("--pack", action="store_true", help="afterwards replace the linears by PackedLinear and report sizes / decode latency")
     ap.add_argument("--ppl", action="store_true", help="also evaluate synthetic-token perplexity before/after")
     args = ap.parse_args()
 
@@ -76,6 +77,32 @@ def main():
                peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     if args.ppl:
         out["ppl_slim_fp32loss"] = eval_ppl_wikitext(model, test, 1, dev, fp32_loss=True)
+    if args.pack:
+        from slim.lora import quantize_lora
+        from slim_amd.packed import pack_model
+        quantize_lora(model, bitwidth=4, lora_tile_size=256)
+        ids = torch.randint(0, cfg["vocab_size"], (1, 64), device=dev)
+        with torch.no_grad():
+            ref = model(ids).logits
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(3):
+                model(ids[:, :1])
+            torch.cuda.synchronize()
+            out["emulated_1token_forward_ms"] = round((time.time() - t0) / 3 * 1e3, 2)
+            dense, packed = pack_model(model)
+            got = model(ids).logits
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(3):
+                model(ids[:, :1])
+            torch.cuda.synchronize()
+            out["packed_1token_forward_ms"] = round((time.time() - t0) / 3 * 1e3, 2)
+        out.update(dense_GB=round(dense / 1e9, 2), packed_GB=round(packed / 1e9, 2),
+                   packed_logits_identical_frac=round((got == ref).float().mean().item(), 4),
+                   packed_logits_max_abs_diff=round((got.float() - ref.float()).abs().max().item(), 4))
+        if args.ppl:
+            out["ppl_packed_fp32loss"] = eval_ppl_wikitext(model, test, 1, dev, fp32_loss=True)
     print(json.dumps(out))
 
 
