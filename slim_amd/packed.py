@@ -10,6 +10,14 @@ from . import ops
 from .utils import get_layers_list, find_layers
 
 
+# From this many rows on, the forward expands the packed weight into a transient dense bf16 tensor (one streaming
+# kernel, 2 B written per element) and multiplies with the library GEMM (hipBLASLt through torch.matmul): at large
+# batches the product is MFMA-bound, the expansion costs < 10 % of it, and the tuned library kernel is ahead of
+# the fused one there (measured cross-over between 256 and 1024 rows; tools/forward_bench.py).  Storage stays
+# packed; results are those of the reference's emulated forward bit for bit (same GEMMs, same operands).
+LARGE_BATCH = int(__import__("os").environ.get("SLIM_PACKED_LARGE_BATCH", "512"))
+
+
 class PackedLinear(torch.nn.Module):
     """Drop-in for a compressed nn.Linear (inference only).
 
@@ -109,13 +117,27 @@ class PackedLinear(torch.nn.Module):
         x2 = x.reshape(-1, shape[-1])
         if x2.dtype != torch.bfloat16:
             x2 = x2.to(torch.bfloat16)
-        if self.qL is not None and x2.shape[0] <= 16:
+        if x2.shape[0] >= LARGE_BATCH:
+            y = self._forward_expanded(x2)
+        elif self.qL is not None and x2.shape[0] <= 16:
             y = ops.linear24_forward_q4(x2.contiguous(), self.vals, self.meta, self.sf, self.out_features, self.bias,
                                         self.qL, self.qR, self.rank, self.qblock, self.a_div)
         else:
             y = ops.linear24_forward(x2.contiguous(), self.vals, self.meta, self.sf, self.out_features, self.bias,
                                      self.LeffT, self.ReffT, self.rank, self.a_div)
         return y.reshape(*shape[:-1], self.out_features)
+
+    def _forward_expanded(self, x2):
+        """Large batches: transient dense weight + library GEMMs, adapter terms as in prune.py:303-321."""
+        y = torch.nn.functional.linear(x2, self.dense_weight(), self.bias)
+        if self.rank:
+            r = self.rank
+            xs = x2 if self.a_div == 1.0 else x2 / self.a_div
+            t = torch.matmul(xs, self.LeffT[:r].t())
+            if self.a_div != 1.0:
+                t = t / self.a_div
+            y += torch.matmul(t, self.ReffT[:, :r].t())
+        return y
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, rank={self.rank}, packed 2:4 int4"

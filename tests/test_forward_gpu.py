@@ -118,6 +118,7 @@ CASES = [
 @pytest.mark.parametrize("N,K,r,bias,qblock,batches", CASES)
 def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, batches):
     from slim_amd.packed import PackedLinear
+    import slim_amd.packed as P
     lin = build_layer(N, K, r, seed=N + K + r, bias=bias, quant_block=qblock)
     packed = PackedLinear(lin)
     assert torch.equal(packed.dense_weight(), lin.weight.data)
@@ -142,6 +143,17 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
               f"err ours={err_ours:.4g} torch={err_ref:.4g} identical={(y == ref).float().mean().item():.4f}")
         assert diff <= scale * 2.0 ** -6, (M, diff, scale)
         assert err_ours <= err_ref * 1.25 + 1e-6, (M, err_ours, err_ref)
+        if M >= P.LARGE_BATCH:
+            # that went through the transient dense expansion + library GEMMs: bit-identical to the reference;
+            # the fused tiled kernel on the same batch must meet the bound above too
+            assert torch.equal(y, ref)
+            saved, P.LARGE_BATCH = P.LARGE_BATCH, 10 ** 9
+            try:
+                y2 = packed(x)
+            finally:
+                P.LARGE_BATCH = saved
+            assert (y2.double() - ref.double()).abs().max().item() <= scale * 2.0 ** -6
+            assert (y2.double() - exact).norm().item() <= err_ref * 1.25 + 1e-6
 
 
 def test_packed_forward_leading_dims_and_hooks(ops):
