@@ -51,6 +51,8 @@ def block_stats(wrapped_list):
     median, which the low-rank fit deflates) and the spread of the remaining scales (sizes the Newton-Schulz
     orthonormalisation)."""
     from .lora import MAX_OUTLIER_COLS, _outliers_from_host
+    if not wrapped_list:            # a rank that owns no linear of this block
+        return
     rows, idxs = [], []
     for w in wrapped_list:
         s = torch.sqrt(w.scaler_row)
