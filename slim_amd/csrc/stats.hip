@@ -23,19 +23,19 @@ __global__ __launch_bounds__(256) void colsumsq_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     int64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        u16x8 v0 = *(const u16x8*)(p);
-        u16x8 v1 = *(const u16x8*)(p + ld);
-        u16x8 v2 = *(const u16x8*)(p + 2 * ld);
-        u16x8 v3 = *(const u16x8*)(p + 3 * ld);
-        p += 4 * ld;
+    // eight independent 16-byte loads in flight per lane; the squares are added in row order
+    for (; r + 8 <= r1; r += 8) {
+        u16x8 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float a = bf16_to_f32(v0[j]), b = bf16_to_f32(v1[j]), c = bf16_to_f32(v2[j]), d = bf16_to_f32(v3[j]);
-            acc[j] += a * a;
-            acc[j] += b * b;
-            acc[j] += c * c;
-            acc[j] += d * d;
+        for (int i = 0; i < 8; ++i) v[i] = *(const u16x8*)(p + i * ld);
+        p += 8 * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = bf16_to_f32(v[i][j]);
+                acc[j] += a * a;
+            }
         }
     }
     for (; r < r1; ++r) {
