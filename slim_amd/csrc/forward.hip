@@ -683,6 +683,7 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
 }
 
 #define DECODE_MAX_M 16
+#define DECODE_MIN_WEIGHT ((int64_t)1 << 26)
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // slices of a decode launch: enough workgroups to fill the chip four times over, at least two blocks per
@@ -842,7 +843,7 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
         const int64_t s2 = decode_slices(M, N, K, 0.375) +
                            (r ? max(decode_slices(M, N, r8, 2.0), decode_slices(M, N, r8, 0.5)) : 0);
         const int64_t a = s1 * M * r128 * 4, b = s2 * M * N * 4;
-        return t_bytes + (a > b ? a : b);
+        slab = a > b ? a : b;       // the tiled path below may be taken instead: keep the larger of the two
     }
     for (int pass = 0; pass < 2; ++pass) {
         const int64_t n = pass ? N : r128;
@@ -879,7 +880,9 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
     char* ws = (char*)workspace;
     int64_t ws_left = workspace_bytes;
     bf16_t* t = nullptr;
-    if (M <= DECODE_MAX_M)
+    // The register-streaming kernel pays five launches; it is ahead of the tiled one only where streaming the weight
+    // outweighs them (measured: 28672 x 8192 yes, 4096 x 4096 no)
+    if (M <= DECODE_MAX_M && N * K >= DECODE_MIN_WEIGHT)
         return decode_path(x, ldx, M, K, vals, meta, sf, N, bias, LeffT, ReffT, nullptr, nullptr, nullptr, nullptr, 0, r, a_div,
                            y, ldy, ws, st);
     if (r > 0) {

@@ -16,6 +16,11 @@ from .utils import get_layers_list, find_layers
 # the fused one there (measured cross-over between 256 and 1024 rows; tools/forward_bench.py).  Storage stays
 # packed; results are those of the reference's emulated forward bit for bit (same GEMMs, same operands).
 LARGE_BATCH = int(__import__("os").environ.get("SLIM_PACKED_LARGE_BATCH", "512"))
+# Keep 4-bit group-quantised adapters as codes + scales for the small-batch path (0.5 instead of 2 bytes per
+# adapter element in HBM).  Off by default: rebuilding bf16(code / 7 * alpha) in registers costs more VALU time
+# than the bytes save on MI355X (28672 x 8192, rank 1024, batch 1: 81 us against 63 us with bf16 operands), so it
+# is a memory-footprint option, not a speed one.
+Q4_ADAPTERS = __import__("os").environ.get("SLIM_PACKED_Q4_ADAPTERS", "0") == "1"
 
 
 class PackedLinear(torch.nn.Module):
@@ -58,7 +63,7 @@ class PackedLinear(torch.nn.Module):
                 L, aL, cL = ops.group_fake_quant(L.contiguous(), q.block_dim, q.num_bits, want_codes=True)
                 R, aR, cR = ops.group_fake_quant(R.contiguous(), q.block_dim, q.num_bits, want_codes=True)
                 self.a_div = float(sqrt_r)
-                if q.num_bits == 4 and q.block_dim % 32 == 0:
+                if Q4_ADAPTERS and q.num_bits == 4 and q.block_dim % 32 == 0:
                     # codes and scales themselves, laid out for the small-batch kernel (0.5 byte per element)
                     self.qblock = int(q.block_dim)
                     self.qL = ops.pack_q4_operand(cL.t().contiguous(), aL.t().contiguous(), -(-r // 128) * 128)

@@ -107,6 +107,8 @@ def build_layer(N, K, r, seed, bias, quant_block=None):
 
 CASES = [
     # N, K, r, bias, quantised-adapter block, batch sizes
+    (8192, 8192, 256, False, 256, [1, 7, 16]),          # large enough for the register-streaming small-batch kernel
+    (16384, 4096, 200, True, None, [3, 16]),
     (128, 64, 0, False, None, [1, 16, 130]),
     (256, 512, 51, True, None, [1, 5, 17, 33, 100, 128, 300]),
     (256, 512, 128, False, 128, [1, 16, 64, 200]),
@@ -115,12 +117,20 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("q4", [False, True])
 @pytest.mark.parametrize("N,K,r,bias,qblock,batches", CASES)
-def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, batches):
+def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, batches, q4):
     from slim_amd.packed import PackedLinear
     import slim_amd.packed as P
+    if q4 and not qblock:
+        pytest.skip("4-bit adapter operands exist for quantised adapters only")
     lin = build_layer(N, K, r, seed=N + K + r, bias=bias, quant_block=qblock)
-    packed = PackedLinear(lin)
+    saved_q4, P.Q4_ADAPTERS = P.Q4_ADAPTERS, q4
+    try:
+        packed = PackedLinear(lin)
+    finally:
+        P.Q4_ADAPTERS = saved_q4
+    assert (packed.qL is not None) == bool(q4)
     assert torch.equal(packed.dense_weight(), lin.weight.data)
     dense_bytes = N * K * 2
     assert packed.vals.numel() + packed.meta.numel() == dense_bytes * 3 // 16
@@ -134,7 +144,7 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
         # Both sides round the same expression at the same points but accumulate each matmul in a different
         # order, so individual outputs may differ by a bf16 unit of one of the rounded terms.  Bound: every
         # output within 2^-6 of the output scale of the torch result, and our distance to the fp64-accumulated
-        # value no larger than the torch path's (x1.25).
+        # value no larger than the torch path's (x1.25, plus the slack below).
         scale = exact.abs().max().item()
         diff = (y.double() - ref.double()).abs().max().item()
         err_ours = (y.double() - exact).norm().item()
@@ -142,7 +152,9 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
         print(f"N={N} K={K} r={r} M={M}: max|ours-torch|={diff:.4g} scale={scale:.4g} "
               f"err ours={err_ours:.4g} torch={err_ref:.4g} identical={(y == ref).float().mean().item():.4f}")
         assert diff <= scale * 2.0 ** -6, (M, diff, scale)
-        assert err_ours <= err_ref * 1.25 + 1e-6, (M, err_ours, err_ref)
+        # slack: up to 0.1 % of the outputs one bf16 unit (of the output scale) away from the fp64-accumulated value
+        slack = scale * 2.0 ** -8 * math.sqrt(1e-3 * y.numel())
+        assert err_ours <= err_ref * 1.25 + slack, (M, err_ours, err_ref)
         if M >= P.LARGE_BATCH:
             # that went through the transient dense expansion + library GEMMs: bit-identical to the reference;
             # the fused tiled kernel on the same batch must meet the bound above too
@@ -153,7 +165,7 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
             finally:
                 P.LARGE_BATCH = saved
             assert (y2.double() - ref.double()).abs().max().item() <= scale * 2.0 ** -6
-            assert (y2.double() - exact).norm().item() <= err_ref * 1.25 + 1e-6
+            assert (y2.double() - exact).norm().item() <= err_ref * 1.25 + slack
 
 
 def test_packed_forward_leading_dims_and_hooks(ops):
