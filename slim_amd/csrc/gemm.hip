@@ -61,8 +61,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     const int orig = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+    // consecutive tiles share the panel of the operand with MORE tiles and walk over the few tiles of the other one,
+    // so the large operand (the N x K error matrix in the sketch products) is streamed once and the small one is
+    // served by L2
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tm, tn;
+    if (tiles_m < tiles_n) {
+        tn = wgid / tiles_m;
+        tm = wgid % tiles_m;
+    } else {
+        tm = wgid / tiles_n;
+        tn = wgid % tiles_n;
+    }
     const int row0 = tm * BM, col0 = tn * BN;
 
     if (g.batch > 1) {     // strided batch: blockIdx.z selects the problem

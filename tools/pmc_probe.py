@@ -1,40 +1,73 @@
-"""Single-threaded pass over the kernels of the path on one 4096 x 4096 linear (statistics over 16 x 2048 tokens,
-mask, histograms + scale searches, error matrix, low-rank fit, residual, re-quantisation, packing, forward), meant to
-be run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (one counter per run).  Everything is enqueued from
-the main thread on one stream: counter collection serialises dispatches and is not exercised with several
-launching threads here.  tools/pmc_summarize.py turns the two CSVs into per-kernel HBM bytes per launch."""
+"""Solver-free replay of the launches of one bench step (one LLaMA-2-7B block), for `rocprofv3 --pmc FETCH_SIZE` /
+`--pmc WRITE_SIZE` (one counter per run; tools/pmc_summarize.py turns the two CSVs into HBM bytes per launch).
+
+Counter collection on the bench itself aborts inside rocSOLVER (SIGSEGV in the eigen-solver call under
+`rocprofv3 --pmc`), so this script issues the library's own kernels with the shapes and counts of a bench step --
+statistics (4 distinct inputs), mask, histograms, error matrix, transposes, and per linear the 13 sketch products and
+13 x 4 Newton-Schulz steps (Gram with the fit's split-K, l x l square, apply) on random operands, residual and
+re-quantisation -- everything from the main thread on one stream."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SLIM_COMPRESS_STREAMS"] = "1"
 import bench as B
 from slim_amd import ops, _lib
-from slim_amd import prune as P
-from slim_amd.packed import PackedLinear
-from slim_amd.quantization.quantization import Quantizer
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 _lib.load()
-N = K = 4096
-lin = torch.nn.Linear(K, N, bias=False, device=dev, dtype=torch.bfloat16)
-lin.weight.requires_grad_(False)
-lin.weight.data = B.synth_weight(N, K, 100, dev)
-X = B.synth_acts(16, 2048, K, 1, dev)
-for rep in range(2):                       # first pass warms code objects and allocator
-    lin._forward_hooks.clear()
-    lin.weight.data = B.synth_weight(N, K, 100, dev)
-    wrapped = B.collect_stats(lin, X)
-    wrapped.scaler_row = ops.shift_zeros(wrapped.scaler_row)
-    P.block_stats([wrapped])
-    P.compress_linears([("probe", lin, wrapped)], dev, 2, 4, sparsity_ratio=0.5,
-                       quantizer=Quantizer("weight", num_bits=4, slim_quant=True), lora_rank=0.1, slim_lora=True,
-                       quantize_lora=True, lora_tile_size=256, n_streams=1)
-    packed = PackedLinear(lin)
-    for M in (1, 16, 4096):
-        packed(torch.randn(M, K, device=dev, dtype=torch.bfloat16))
+L_DIM, RANK, NSAMP, SEQ = 640, 512, 128, 2048
+
+
+def bf(*shape):
+    return torch.randn(*shape, device=dev).to(torch.bfloat16)
+
+
+def gram_splits(rows):
+    tiles = 25
+    splits = min((512 + tiles - 1) // tiles, (rows + 63) // 64 // 4, 16)
+    return max(splits, 1)
+
+
+def ns_step(X, Xt):
+    rows = X.shape[0]
+    _, G16 = ops.gemm_nt_splitk(Xt, Xt, gram_splits(rows))                      # Gram, split-K as in the fit
+    ops.gemm_nt(G16, G16, out_f32=True)                                         # l x l square
+    _, Y, Yt = ops.gemm_nt(X, G16, out_bf16=True, out_t=True)                   # apply (polynomial stands in as G16)
+    return Y, Yt
+
+
+acts = {}
+for rep in range(2):                 # the first pass warms code objects and the allocator
+    for (name, N, K, src) in B.LLAMA2_7B_BLOCK:
+        if rep == 0 and src not in acts:
+            acts[src] = B.synth_acts(NSAMP, SEQ, K, 1 + len(acts), dev)
+    for src, X in acts.items():
+        ops.colsumsq(X.reshape(-1, X.shape[-1]), NSAMP)
+    for (name, N, K, src) in B.LLAMA2_7B_BLOCK:
+        W = B.synth_weight(N, K, 100, dev)
+        s = torch.rand(K, device=dev) + 0.5
+        mask = ops.mask_nm(W, s, 2, 4)
+        hist = ops.hist_abs(W)
+        sf = ops.quant_search(hist, max(512, min(W.numel() // 1000, 20000)), 4)[2].reshape(1)
+        _, E = ops.error_matrix(W, mask, s, sf, 4)
+        Et = ops.transpose(E)
+        Qn, Qnt = bf(N, L_DIM), bf(L_DIM, N)
+        Pk, Pkt = bf(K, L_DIM), bf(L_DIM, K)
+        for it in range(7):
+            ops.gemm_nt(Pkt, E, out_bf16=True, out_t=True)                      # Y^T = P^T E^T
+            for _ in range(4):
+                ns_step(Qn, Qnt)
+        for it in range(7):
+            ops.gemm_nt(Qnt, Et, out_bf16=True, out_t=True)                     # Z^T = Q^T E
+            if it < 6:
+                for _ in range(4):
+                    ns_step(Pk, Pkt)
+        U, Lf = bf(N, RANK), bf(K, RANK)
+        Wn = ops.lowrank_residual(U, Lf, W, mask)
+        hist = ops.hist_abs(Wn)
+        ops.fake_quant_pt(Wn, sf, 4)
     torch.cuda.synchronize()
 print("done")
