@@ -10,11 +10,13 @@ from .quantization.quantization import Quantizer as AutoQuantizer
 from .utils import get_layers_list, find_layers
 
 # Randomized-fit parameters: subspace dimension l = rank + max(FIT_MIN_OVERSAMPLE, rank // 4), and the
-# number of subspace iterations.  With these the reconstruction error of the adapters stays within
-# 1e-3 (relative) of the truncated SVD on SLiM error matrices (tests/test_hip_kernels.py).
+# number of subspace iterations.  SLiM error matrices have a flat spectrum (sigma_r / sigma_(r+128) = 1.04 - 1.06 on
+# LLaMA-2-7B-shaped layers), so the excess over the truncated SVD only halves per iteration: measured on
+# 4096 x 11008 with rank 512 (tools/fit_accuracy.py) 1.6e-3 after 6, 4.7e-4 after 8, < 1e-5 after 10
+# iterations, against a budget of 1e-3; an iteration costs ~0.7 ms of a ~20 ms fit.
 FIT_OVERSAMPLE_DIV = 4
 FIT_MIN_OVERSAMPLE = 64
-FIT_ITERS = 6
+FIT_ITERS = 10
 FIT_SEED = 0
 # orthonormalise the iterates by Cholesky-QR through rocSOLVER instead of Newton-Schulz on MFMA
 FIT_CHOLESKY_QR = os.environ.get("SLIM_FIT_CHOLESKY_QR", "0") == "1"
@@ -39,11 +41,14 @@ def fit_ns_steps(spread):
 
 def ns_steps_for(spread):
     """Quintic Newton-Schulz steps per orthonormalisation from the spread max(s) / median(s) of the saliency
-    scales: the error matrix is (benign matrix) x diag(s), so its conditioning inside the leading subspace is
-    bounded by about 8 x spread; each step lifts a singular value by up to 3.44x."""
+    scales.  The error matrix is (benign matrix) x diag(s): its largest singular values come from the columns with
+    the largest scale, the bulk from the typical ones, so the conditioning of an iterate inside the leading
+    subspace is of the order of the spread (measured: 14 at spread ~40).  Each step lifts a singular value by up
+    to 3.44x; three steps are the floor (two fail at a conditioning of 14, tools/fit_accuracy.py).  Intermediate
+    bases only need to be well conditioned -- the last one is finished by an exact Cholesky-QR."""
     import math
-    kappa = 8.0 * max(float(spread), 1.0)
-    return int(min(12, max(4, math.ceil(math.log(kappa) / math.log(3.44)))))
+    kappa = 2.0 * max(float(spread), 4.0)
+    return int(min(12, max(3, math.ceil(math.log(kappa) / math.log(3.44)))))
 
 
 # Columns of the error matrix whose saliency scale exceeds OUTLIER_RATIO x the median are split off and
