@@ -57,21 +57,21 @@ int slim_prof_begin(const char* name, hipStream_t st, double bytes, double flops
     r.bytes = bytes;
     r.flops = flops;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
 }
 
 void slim_prof_end(int token, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (token >= 0 && token < (int)g_prof.size()) hipEventRecord(g_prof[token].b, st);
+    if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, st);
 }
 
 extern "C" int slim_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
     g_slim_prof_on = on != 0;
