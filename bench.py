@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=7, help="HIP streams the linears of a block are spread over")
+    ap.add_argument("--gemm-tile", type=int, default=-1, help="tuning aid: force one GEMM tile variant (slim_gemm_set_tile)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,15 +191,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _lib.query("slim_gemm_set_tile", args.gemm_tile)
     for _ in range(args.warmup):
         step()
     barrier()
-    _lib.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # The same steps once more with the in-library timer on (a HIP-event pair around every launch, on the launch's own
+    # stream): the per-family table.  Kept out of the timed region above because the event packets themselves cost
+    # dispatch slots on a step made of thousands of short launches; the instrumented time is reported beside it.
+    _lib.profile_enable(True)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt_instrumented = time.perf_counter() - t1
     prof = _lib.profile_summary()
     _lib.profile_enable(False)
     # One more step, untimed, on a single stream: with seven streams in flight a HIP-event pair around a launch
@@ -235,7 +245,7 @@ def main():
                 print(f"[bench]   {r['name']:<20} n={r['count']:<5} total={r['total_ms']:9.2f} ms  avg={r['avg_us']:9.1f} us  "
                       f"{r['gbs']:8.1f} GB/s  {r['tfs']:7.1f} TFLOP/s", file=sys.stderr)
             return out
-        rows = table(prof, f"per-family timing over the {args.steps} timed steps, {args.streams} streams (rank 0)")
+        rows = table(prof, f"per-family timing over {args.steps} instrumented steps, {args.streams} streams (rank 0)")
         rows_single = table(prof_single, "per-family timing of one extra step on a single stream") if prof_single else rows
         own = [r for r in rows_single if not r["name"].startswith("solver_")]
         dom = own[0] if own else None
@@ -258,7 +268,8 @@ def main():
                                    "SLiM-Quant 4-bit + lora_rank 0.1 (r=512, tile 256), "
                                    f"{args.nsamples}x{args.seqlen} synthetic calibration activations resident in HBM",
                        "partition": f"layer-level over {world} rank(s)" + (" + RCCL broadcast of shards" if world > 1 else ""),
-                       "wallclock_7b_extrapolated_s": ms_per_step * 32 / 1e3},
+                       "wallclock_7b_extrapolated_s": ms_per_step * 32 / 1e3,
+                       "ms_per_step_with_event_timers": dt_instrumented / args.steps * 1e3},
             "roofline": roofline,
             "kernels": {r["name"]: {"count": r["count"], "total_ms": round(r["total_ms"], 3), "avg_us": round(r["avg_us"], 2),
                                     "GBps": round(r["gbs"], 1), "TFLOPps": round(r["tfs"], 2)} for r in rows},

@@ -26,6 +26,7 @@ extern "C" {
 #define SLIM_FIT_INFO_WORDS 64
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_ONE_SIDED 2   /* re-orthonormalise only the row-side iterate (once per full iteration) */
+#define SLIM_FIT_LIBRARY_EIGH 4 /* Rayleigh-Ritz eigenproblem through rocSOLVER syevd instead of slim_eigh_f32's method */
 
 int slim_abi_version(void);
 const char* slim_last_error(void); /* host string, valid until the next failing call on this thread */
@@ -150,6 +151,23 @@ int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, i
 int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
                              float alpha, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16, int splits,
                              float* slab, void* stream);
+
+/* Tuning aid: force the workgroup tile of every following GEMM launch in this process (0: 128x128, 1: 128x64,
+ * 2: 64x128, 3: 64x64; anything else: chosen per problem, the default).  Results do not depend on the tile. */
+void slim_gemm_set_tile(int tile);
+/* Tuning aid: while buf (device memory, 8 * capacity_workgroups int64) is set, every GEMM launch records, for each
+ * workgroup below the capacity, 100 MHz timestamps of kernel entry, first tile staged, K-loop done and epilogue done.
+ * NULL switches it off (the default). */
+void slim_gemm_set_trace(void* buf, int capacity_workgroups);
+
+/* Eigenvalues (ascending) and the `top` leading eigenvectors of a symmetric fp32 matrix G [n, n] (both triangles
+ * given, destroyed), n a multiple of 4 in [4, 2048].  On return row n-1-i of G is the eigenvector of the i-th
+ * largest eigenvalue for i < top; info[0] = status of the tridiagonal solver (0 = converged).  This is the
+ * Rayleigh-Ritz step of slim_lowrank_fit (the part of torch.svd at slim/lora.py:172 that remains after the
+ * subspace iteration): Householder tridiagonalisation with one launch per column, rocSOLVER stedc, one GEMM. */
+int64_t slim_eigh_workspace_bytes(int n);
+int slim_eigh_f32(float* G, int n, int top, float* evals, int32_t* info, void* workspace, int64_t workspace_bytes,
+                  void* stream);
 
 /* Orthonormal basis Q [rows, l] (and Q^T) of the column space of X [rows, l] (Xt = X^T), either by
  * ns_quintic + ns_cubic Newton-Schulz steps on MFMA or (flags & SLIM_FIT_CHOLESKY_QR) by Cholesky-QR.

@@ -68,9 +68,10 @@ __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     union { uint32_t u; float f; } c;
     c.f = f;
-    if ((c.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((c.u >> 16) | 0x0040u);
-    uint32_t r = c.u + 0x7fffu + ((c.u >> 16) & 1u);
-    return (bf16_t)(r >> 16);
+    // branch-free (a select): inside store loops a branch per element costs far more than the arithmetic
+    const uint32_t nan = (c.u >> 16) | 0x0040u;
+    const uint32_t r = (c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16;
+    return (bf16_t)(((c.u & 0x7fffffffu) > 0x7f800000u) ? nan : r);
 }
 
 __host__ __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }

@@ -1,0 +1,287 @@
+// Eigen-decomposition of a small dense symmetric fp32 matrix (the l x l Rayleigh-Ritz matrix of the low-rank fit,
+// l of a few hundred to two thousand) with a short launch chain.
+//
+// The library routine for this (rocSOLVER syevd) spends most of its time in a blocked Householder
+// tridiagonalisation that issues four to five tiny kernels per column; at these sizes the matrix lives in L2 /
+// Infinity Cache and the chain is bound by the number of dependent launches, not by arithmetic.  Here the reduction
+// to tridiagonal form takes ONE launch per column: the kernel of column j
+//   (1) finishes reflector j-1: w = p - (tau/2)(p.v) v from the matrix-vector product p = tau A v that the
+//       previous launch left in memory (every workgroup does this redundantly, it is O(n)),
+//   (2) forms row j of the updated matrix A - v w^T - w v^T on the fly and derives reflector j from it,
+//   (3) applies the rank-2 update of reflector j-1 to its share of the trailing rows while it accumulates their
+//       dot products with the new v (the next p), and
+//   (4) multiplies its share of the rows of the accumulated orthogonal matrix Q by reflector j (Q <- Q H_j is
+//       row-local, so no back-transformation pass over n reflectors is needed afterwards).
+// The tridiagonal problem then goes to rocSOLVER's divide-and-conquer solver (stedc) and the wanted eigenvectors
+// are Q times its eigenvectors (one fp32 GEMM).
+#include "common.hpp"
+#include "../../include/slim_hip.h"
+#include "eigh.hpp"
+#include "solver.hpp"
+
+#define TD_THREADS 256
+#define TD_ROWS_PER_WAVE 2
+
+struct TridiagArgs {
+    float* A;      // [batch][n, n] symmetric, both triangles valid; destroyed
+    float* Q;      // [batch][n, n] accumulated reflectors (row-major), written from column 0 on
+    float* vbuf;   // [batch][2, n] reflector vectors, double-buffered by column parity
+    float* pbuf;   // [batch][2, n] tau * A v, double-buffered
+    float* taus;   // [batch][n]
+    float* d;      // [batch][n] diagonal of the tridiagonal matrix
+    float* e;      // [batch][n] off-diagonal (n - 1 used)
+    int n, j;
+};
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    __syncthreads();     // protects `red` against the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// MAXV: float4 chunks per lane per row, n <= 256 * MAXV
+template <int MAXV>
+__global__ __launch_bounds__(TD_THREADS) void tridiag_step_kernel(TridiagArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double red[4];
+    const int n = g.n, j = g.j, t = threadIdx.x;
+    {
+        const int64_t bz = blockIdx.y;
+        g.A += bz * n * n;
+        g.Q += bz * n * n;
+        g.vbuf += bz * 2 * n;
+        g.pbuf += bz * 2 * n;
+        g.taus += bz * n;
+        g.d += bz * n;
+        g.e += bz * n;
+    }
+    float* vp = sm;            // previous reflector vector (entries >= j, vp[j] == 1)
+    float* wp = sm + n;        // its w
+    float* v = sm + 2 * n;     // this column's reflector (zero up to and including j)
+
+    // (1) finish reflector j-1
+    if (j > 0) {
+        const float tau_p = g.taus[j - 1];
+        const float* vg = g.vbuf + ((j - 1) & 1) * n;
+        const float* pg = g.pbuf + ((j - 1) & 1) * n;
+        double dot = 0.0;
+        for (int k = j + t; k < n; k += TD_THREADS) {
+            const float vv = vg[k], pp = pg[k];
+            vp[k] = vv;
+            wp[k] = pp;
+            dot += (double)vv * (double)pp;
+        }
+        dot = block_sum_d(dot, red);
+        const float alpha = -0.5f * tau_p * (float)dot;
+        for (int k = j + t; k < n; k += TD_THREADS) wp[k] += alpha * vp[k];
+        __syncthreads();
+    }
+
+    // (2) row j of the updated matrix -> d[j] and reflector j from its entries right of the diagonal
+    {
+        const float* rowj = g.A + (int64_t)j * n;
+        const float wj = j > 0 ? wp[j] : 0.f;
+        double nrm = 0.0;
+        for (int k = j + t; k < n; k += TD_THREADS) {
+            float x = rowj[k];
+            if (j > 0) x -= wp[k] + wj * vp[k];      // v'[j] w'[k] + w'[j] v'[k] with v'[j] == 1
+            v[k] = x;
+            if (k >= j + 2) nrm += (double)x * (double)x;
+        }
+        nrm = block_sum_d(nrm, red);                 // its barriers also publish v[]
+        const float dj = v[j], a1 = v[j + 1];
+        const float xnorm = (float)sqrt(nrm);
+        float beta, tau, scale;
+        if (xnorm == 0.f) {
+            tau = 0.f;
+            beta = a1;
+            scale = 0.f;
+        } else {
+            beta = -copysignf(hypotf(a1, xnorm), a1);
+            tau = (beta - a1) / beta;
+            scale = 1.f / (a1 - beta);
+        }
+        __syncthreads();                             // every thread has read v[j], v[j + 1]
+        for (int k = j + t; k < n; k += TD_THREADS) v[k] = k <= j ? 0.f : (k == j + 1 ? 1.f : v[k] * scale);
+        for (int k = t; k < j; k += TD_THREADS) v[k] = 0.f;
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            float* vg = g.vbuf + (j & 1) * n;
+            for (int k = j + 1 + t; k < n; k += TD_THREADS) vg[k] = v[k];
+            if (t == 0) {
+                g.taus[j] = tau;
+                g.d[j] = dj;
+                g.e[j] = beta;
+            }
+        }
+
+        // (3) + (4): one row per wave at a time
+        const int lane = t & 63, wave = t >> 6;
+        const int nA = n - j - 1;                              // trailing rows j+1 .. n-1
+        const int nQ = (j == 0 || tau != 0.f) ? n : 0;         // Q is created at j == 0
+        const int mstart = (j + 1) / 256;
+        float* pg = g.pbuf + (j & 1) * n;
+#pragma unroll 1
+        for (int rr = 0; rr < TD_ROWS_PER_WAVE; ++rr) {
+            const int task = ((int)blockIdx.x * (TD_THREADS / 64) + wave) * TD_ROWS_PER_WAVE + rr;
+            if (task < nA) {
+                const int i = j + 1 + task;
+                float* row = g.A + (int64_t)i * n;
+                const float vi = j > 0 ? vp[i] : 0.f, wi = j > 0 ? wp[i] : 0.f;
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < MAXV; ++m) {
+                    const int k = 256 * m + 4 * lane;
+                    if (m < mstart || k >= n) continue;
+                    f32x4 a = *(const f32x4*)(row + k);
+                    const f32x4 vv = *(const f32x4*)(v + k);
+                    if (j > 0) {
+                        const f32x4 w4 = *(const f32x4*)(wp + k), v4 = *(const f32x4*)(vp + k);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (k + c >= j + 1) a[c] -= vi * w4[c] + wi * v4[c];
+                        *(f32x4*)(row + k) = a;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc += a[c] * vv[c];     // v is zero left of column j + 1
+                    if (i == n - 1 && k <= n - 1 && n - 1 < k + 4) g.d[n - 1] = a[(n - 1) - k];   // final once j == n - 2
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) pg[i] = tau * acc;
+            } else if (task < nA + nQ) {
+                const int i = task - nA;
+                float* row = g.Q + (int64_t)i * n;
+                const int ms = j == 0 ? 0 : mstart;
+                f32x4 q[MAXV];
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < MAXV; ++m) {
+                    const int k = 256 * m + 4 * lane;
+                    if (m < ms || k >= n) continue;
+                    if (j == 0) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) q[m][c] = (k + c == i) ? 1.f : 0.f;
+                    } else {
+                        q[m] = *(const f32x4*)(row + k);
+                    }
+                    const f32x4 vv = *(const f32x4*)(v + k);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc += q[m][c] * vv[c];
+                }
+                const float s = tau * wave_sum(acc);
+#pragma unroll
+                for (int m = 0; m < MAXV; ++m) {
+                    const int k = 256 * m + 4 * lane;
+                    if (m < ms || k >= n) continue;
+                    const f32x4 vv = *(const f32x4*)(v + k);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) q[m][c] -= s * vv[c];
+                    *(f32x4*)(row + k) = q[m];
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
+
+struct EighWs {
+    float *Q, *C, *e, *vbuf, *pbuf, *taus;
+    int64_t total;
+};
+static EighWs eigh_ws(char* base, int n, int batch) {
+    EighWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) {
+        char* p = base ? base + o : nullptr;
+        o += al256(bytes * batch);
+        return (float*)p;
+    };
+    w.Q = take((int64_t)n * n * 4);
+    w.C = take((int64_t)n * n * 4);
+    w.e = take((int64_t)n * 4);
+    w.vbuf = take((int64_t)2 * n * 4);
+    w.pbuf = take((int64_t)2 * n * 4);
+    w.taus = take((int64_t)n * 4);
+    w.total = o;
+    return w;
+}
+
+bool slim_eigh_supported(int n) {
+    rb_handle h = nullptr;
+    if (n < 3 || n > SLIM_EIGH_MAX_N || n % 4 != 0) return false;
+    if (solver_handle(nullptr, &h) != SLIM_OK) return false;
+    return g_solver.stedc && g_solver.sgemm;
+}
+
+int64_t slim_eigh_ws_bytes(int n, int batch) { return eigh_ws(nullptr, n, batch).total; }
+
+template <int MAXV>
+static void launch_step(const TridiagArgs& a, int batch, hipStream_t st) {
+    const int n = a.n, j = a.j;
+    const int tasks = (n - j - 1) + (j == n - 2 ? 0 : n);
+    const int per_wg = (TD_THREADS / 64) * TD_ROWS_PER_WAVE;
+    dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg), (unsigned)batch);
+    hipLaunchKernelGGL(tridiag_step_kernel<MAXV>, grid, dim3(TD_THREADS), (size_t)3 * n * sizeof(float), st, a);
+}
+
+int slim_eigh_launch(float* G, int n, int batch, int top, float* evals, int* info, int info_stride, void* ws,
+                     int64_t ws_bytes, hipStream_t st) {
+    SLIM_REQUIRE(G && evals && info && ws && batch >= 1 && batch <= 65535, "slim_eigh: bad arguments");
+    SLIM_REQUIRE(n >= 3 && n <= SLIM_EIGH_MAX_N && n % 4 == 0, "slim_eigh: n must be a multiple of 4 in [4, 2048]");
+    SLIM_REQUIRE(top >= 1 && top <= n, "slim_eigh: bad number of wanted eigenvectors");
+    SLIM_REQUIRE(((uintptr_t)G % 16) == 0 && ((uintptr_t)ws % 16) == 0, "slim_eigh: buffers must be 16-byte aligned");
+    SLIM_REQUIRE(ws_bytes >= slim_eigh_ws_bytes(n, batch), "slim_eigh: workspace too small");
+    rb_handle h = nullptr;
+    int rc = solver_handle(st, &h);
+    if (rc) return rc;
+    SLIM_REQUIRE(g_solver.stedc && g_solver.sgemm, "slim_eigh: rocsolver_sstedc / rocblas_sgemm not available");
+    EighWs w = eigh_ws((char*)ws, n, batch);
+    {
+        SLIM_PROF("eigh_tridiag", st, 0.0, (4.0 / 3.0 + 2.0) * n * (double)n * n * batch);
+        TridiagArgs a{G, w.Q, w.vbuf, w.pbuf, w.taus, evals, w.e, n, 0};
+        for (int j = 0; j <= n - 2; ++j) {
+            a.j = j;
+            if (n <= 768) launch_step<3>(a, batch, st);
+            else if (n <= 1280) launch_step<5>(a, batch, st);
+            else launch_step<8>(a, batch, st);
+        }
+        SLIM_LAUNCH_CHECK();
+    }
+    {
+        SLIM_PROF("solver_stedc", st, 0.0, 4.0 * n * (double)n * n * batch);
+        for (int b = 0; b < batch; ++b)
+            if (g_solver.stedc(h, RB_EVECT_TRIDIAGONAL, n, evals + (int64_t)b * n, w.e + (int64_t)b * n,
+                               w.C + (int64_t)b * n * n, n, info + (int64_t)b * info_stride) != 0) {
+                slim_set_error("rocsolver_sstedc failed");
+                return SLIM_ERR_SOLVER;
+            }
+    }
+    {
+        // eigenvector k of G = Q c_k.  Column-major view: the buffer holding row-major Q is Q^T, the solver's C holds c_k
+        // as column k, and column k of the product lands where the row-major result keeps "row k = eigenvector k".
+        SLIM_PROF("eigh_backproduct", st, 0.0, 2.0 * n * (double)n * top * batch);
+        const float one = 1.f, zero = 0.f;
+        const int64_t off = (int64_t)(n - top) * n;
+        for (int b = 0; b < batch; ++b)
+            if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, n, top, n, &one, w.Q + (int64_t)b * n * n, n,
+                               w.C + (int64_t)b * n * n + off, n, &zero, G + (int64_t)b * n * n + off, n) != 0) {
+                slim_set_error("rocblas_sgemm failed");
+                return SLIM_ERR_SOLVER;
+            }
+    }
+    return SLIM_OK;
+}
+
+extern "C" int64_t slim_eigh_workspace_bytes(int n) { return n > 0 ? slim_eigh_ws_bytes(n, 1) : 0; }
+
+// Eigenvalues (ascending) and the `top` leading eigenvectors of the symmetric matrix G [n, n] (fp32, both triangles
+// given).  On return row n-1-i of G is the eigenvector of the i-th largest eigenvalue, for i < top; the other rows
+// hold no result.  info [1] receives the tridiagonal solver's status word (0 = converged).
+extern "C" int slim_eigh_f32(float* G, int n, int top, float* evals, int32_t* info, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    return slim_eigh_launch(G, n, 1, top, evals, info, 1, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -3,8 +3,8 @@
 // every product of the low-rank fit is arranged to have (the tall matrices are kept both
 // as X and X^T; this kernel can emit C, bf16(C) and bf16(C)^T in one pass for that purpose).
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave as 4x4
-// v_mfma_f32_16x16x32_bf16 fragments), K-step 64, register-staged global->LDS copies with
+// Tiling: 128x128 (or, for small problems, 128x64 / 64x128 / 64x64) output tile per 256-thread workgroup (2x2 waves,
+// up to 64x64 per wave as 4x4 v_mfma_f32_16x16x32_bf16 fragments), K-step 64, register-staged global->LDS copies with
 // the next tile's loads issued before the current tile's MFMAs, two LDS buffers, one barrier
 // per K-step.  LDS rows are padded by 8 elements (144-byte stride) so the 16 rows read by a
 // ds_read_b128 lane group fall on distinct banks.
@@ -13,17 +13,28 @@
 
 #include "gemm.hpp"
 
-#define BM 128
-#define BN 128
 #define BK 64
 #define LDS_STRIDE (BK + 8)
 
+// Tile shapes: a 256-thread workgroup is 2 x 2 waves, a wave owns FM x FN fragments of 16 x 16, so the workgroup tile
+// is (32 FM) x (32 FN).  The big tile has the best reuse; the small ones exist because the products of the fit are
+// small (a few hundred tiles at most) and each workgroup's K-loop is bound by load latency: more, smaller workgroups
+// keep more loads in flight per CU and fill the 256 CUs.
+// Variants 0-3 stage tiles through registers (one K-step ahead, padded LDS rows); 4+ use LDS-DMA, several stages deep.
+enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, DMA_128x128_S3, DMA_128x64_S3, DMA_64x128_S3, DMA_64x64_S4,
+       DMA_128x128_K32_S6, DMA_64x64_K32_S6, DMA_128x128_S4, TILE_COUNT };
+static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128};
+static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 128};
+static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64};
+static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 3, 3, 3, 4, 6, 6, 4};     // 0: register-staged
+
+template <int ROWS>
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
-                                          u16x8 (&r)[4]) {
+                                          u16x8 (&r)[ROWS / 32]) {
     const int t = threadIdx.x;
     const int kc = (t & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         int row = row0 + (t >> 3) + 32 * i;
         row = row < rows ? row : rows - 1;
         const int k = k0 + kc;
@@ -35,26 +46,20 @@ __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t 
     }
 }
 
-__device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[4]) {
+template <int ROWS>
+__device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[ROWS / 32]) {
     const int t = threadIdx.x;
     const int kc = (t & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         const int row = (t >> 3) + 32 * i;
         *(u16x8*)(lds + row * LDS_STRIDE + kc) = r[i];
     }
 }
 
-// FAMILY only names the instantiation (one symbol per shape class of the fit), so that a profiler's per-kernel
-// summary separates them the way the in-library timer does; the code is identical.
-enum { FAM_GRAM, FAM_SMALL, FAM_APPLY, FAM_SKETCH, FAM_BIG, FAM_RESIDUAL, FAM_COUNT };
-template <int FAMILY>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    // buffer b: A tile at smem + b * 2 * BM * LDS_STRIDE, B tile right after it
-    auto As = [&](int b) { return smem + b * 2 * BM * LDS_STRIDE; };
-    auto Bs = [&](int b) { return smem + b * 2 * BM * LDS_STRIDE + BM * LDS_STRIDE; };
-
+// Origin of this workgroup's output tile, and the batch offsets applied to the argument block.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, int& row0, int& col0) {
     // XCD-aware tile order: consecutive hardware workgroup ids round-robin over the 8 XCDs, so give
     // each XCD a contiguous run of tiles (neighbouring tiles share an A or B panel in that XCD's L2).
     const int nwg = gridDim.x;
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         tm = wgid / tiles_n;
         tn = wgid % tiles_n;
     }
-    const int row0 = tm * BM, col0 = tn * BN;
+    row0 = tm * BM;
+    col0 = tn * BN;
 
     if (g.batch > 1) {     // strided batch: blockIdx.z selects the problem
         const int64_t bz = blockIdx.z;
@@ -85,99 +91,380 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         if (g.slab) g.slab += bz * g.sSlab;
     }
 
+}
+
+__device__ __forceinline__ void gemm_stamp(const GemmArgs& g, int slot) {
+    if (g.trace && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)blockIdx.x < g.trace_cap)
+        g.trace[8 * blockIdx.x + slot] = wall_clock64();
+}
+
+// Epilogue shared by the GEMM kernels.  Fragment (i, j) of a wave holds rows wr*16*FM + i*16 + fq*4 + reg, column
+// wc*16*FN + j*16 + fr of the tile: written straight from the fragments every store would be a 2- or 4-byte piece of
+// sixteen different cache lines (and the transposed output a scatter), which costs more than the whole K-loop of the
+// fit's short products.  So the tile goes through LDS (free once the K-loop is done) as fp32 [BM][BN + 1] and leaves
+// in whole rows: 16-byte stores along N for C / the split-K slab / the residual, 16-byte stores along M for C^T.
+// The odd row stride keeps both the row-wise and the column-wise LDS reads conflict-free.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM][FN], float* T, int row0, int col0, int wr,
+                                              int wc, int fr, int fq) {
+    constexpr int BM = 32 * FM, BN = 32 * FN, TS = BN + 1;
+    __syncthreads();                 // every wave is done with the operand tiles
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                T[(wr * 16 * FM + i * 16 + fq * 4 + r) * TS + wc * 16 * FN + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    gemm_stamp(g, 4);
+    const int t = threadIdx.x;
+    const bool split = g.splits > 1;
+    // Row-wise outputs.  On this ISA loads and stores retire through one in-order counter, so a loop that waits for a
+    // load also waits for every earlier store's acknowledgement (a round trip to L2 per iteration): the common case
+    // (no beta, no residual) therefore runs in a loop of its own that contains no global load at all, and the residual
+    // form fetches all its W / mask pieces before its first store.
+    if (split || g.C32 || g.C16 || g.Wn) {
+        constexpr int TPR = BN / 4;                    // threads per tile row, four columns each
+        constexpr int RSTEP = 256 / TPR, ITERS = BM / RSTEP;
+        const int c = (t % TPR) * 4, col = col0 + c;
+        const int nc = g.N - col;                      // valid columns from `col` on
+        const int rt = t / TPR;
+        if (nc > 0) {
+            if (split) {
+                float* slab = g.slab + (int64_t)blockIdx.y * g.M * g.N;
+                const bool v32 = (g.N & 3) == 0 && ((uintptr_t)slab & 15) == 0 && nc >= 4;
+                float v[ITERS][4];
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[it][u] = T[(rt + it * RSTEP) * TS + c + u];
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int row = row0 + rt + it * RSTEP;
+                    if (row >= g.M) continue;
+                    float* p = slab + (int64_t)row * g.N + col;
+                    if (v32) *(f32x4*)p = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
+                    else
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nc) p[u] = v[it][u];
+                }
+            } else if (g.Wn) {
+                u16x4 w[ITERS];
+                uint32_t mk[ITERS];
+                const bool vw = nc >= 4 && (g.ldw & 3) == 0 && ((uintptr_t)g.W & 7) == 0 && ((uintptr_t)g.Wn & 7) == 0 &&
+                                (!g.mask || ((uintptr_t)g.mask & 3) == 0);
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int row = row0 + rt + it * RSTEP;
+                    w[it] = u16x4{0, 0, 0, 0};
+                    mk[it] = 0;
+                    if (row >= g.M) continue;
+                    const int64_t o = (int64_t)row * g.ldw + col;
+                    if (vw) {
+                        w[it] = *(const u16x4*)(g.W + o);
+                        if (g.mask) mk[it] = *(const uint32_t*)(g.mask + o);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nc) {
+                                w[it][u] = g.W[o + u];
+                                if (g.mask) mk[it] |= (uint32_t)(g.mask[o + u] != 0) << (8 * u);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int r = rt + it * RSTEP, row = row0 + r;
+                    if (row >= g.M) continue;
+                    const int64_t o = (int64_t)row * g.ldw + col;
+                    bf16_t lr16[4], wn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float v = T[r * TS + c + u] * g.alpha;
+                        lr16[u] = f32_to_bf16(v);
+                        wn[u] = ((mk[it] >> (8 * u)) & 0xffu) ? (bf16_t)0 : f32_to_bf16(bf16_to_f32(w[it][u]) - bf16_to_f32(lr16[u]));
+                    }
+                    if (vw) *(u16x4*)(g.Wn + o) = u16x4{wn[0], wn[1], wn[2], wn[3]};
+                    else
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nc) g.Wn[o + u] = wn[u];
+                    if (g.C16) {
+                        bf16_t* p = g.C16 + (int64_t)row * g.ldc16 + col;
+                        if (nc >= 4 && (g.ldc16 & 3) == 0 && ((uintptr_t)g.C16 & 7) == 0) *(u16x4*)p = u16x4{lr16[0], lr16[1], lr16[2], lr16[3]};
+                        else
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nc) p[u] = lr16[u];
+                    }
+                }
+            } else {
+                const bool v32 = nc >= 4 && (g.ldc32 & 3) == 0 && ((uintptr_t)g.C32 & 15) == 0;
+                const bool v16 = nc >= 4 && (g.ldc16 & 3) == 0 && ((uintptr_t)g.C16 & 7) == 0;
+                auto store_row = [&](int row, const float (&v)[4]) {
+                    if (g.C32) {
+                        float* p = g.C32 + (int64_t)row * g.ldc32 + col;
+                        if (v32) *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+                        else
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nc) p[u] = v[u];
+                    }
+                    if (g.C16) {
+                        bf16_t* p = g.C16 + (int64_t)row * g.ldc16 + col;
+                        if (v16) *(u16x4*)p = u16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                        else
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nc) p[u] = f32_to_bf16(v[u]);
+                    }
+                };
+                if (g.beta != 0.f) {
+                    for (int r = rt; r < BM && row0 + r < g.M; r += RSTEP) {
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            v[u] = T[r * TS + c + u] * g.alpha;
+                            if (u < nc) v[u] += g.beta * g.C32[(int64_t)(row0 + r) * g.ldc32 + col + u];
+                        }
+                        store_row(row0 + r, v);
+                    }
+                } else {
+                    // fully unrolled: all LDS reads are in flight before the first store is built
+                    float v[ITERS][4];
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[it][u] = T[(rt + it * RSTEP) * TS + c + u] * g.alpha;
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it)
+                        if (row0 + rt + it * RSTEP < g.M) store_row(row0 + rt + it * RSTEP, v[it]);
+                }
+            }
+        }
+    }
+    gemm_stamp(g, 5);
+    if (g.Ct16 && !split) {
+        // a wave writes eight rows of C^T (tile columns) at a time, 8 lanes x 16 bytes = 128 contiguous bytes each
+        const int lane = t & 63, wave = t >> 6;
+        const bool vt = (g.ldct & 7) == 0 && ((uintptr_t)g.Ct16 & 15) == 0;
+#pragma unroll
+        for (int cbi = 0; cbi < BN / 32; ++cbi) {
+            const int c = cbi * 32 + wave * 8 + (lane & 7), col = col0 + c;
+            bf16_t o[BM / 64][8];
+#pragma unroll
+            for (int half = 0; half < BM / 64; ++half)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    o[half][u] = f32_to_bf16(T[(half * 64 + (lane >> 3) * 8 + u) * TS + c] * g.alpha);
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int half = 0; half < BM / 64; ++half) {
+                const int row = row0 + half * 64 + (lane >> 3) * 8;
+                if (row >= g.M) continue;
+                bf16_t* p = g.Ct16 + (int64_t)col * g.ldct + row;
+                if (row + 7 < g.M && vt)
+                    *(u16x8*)p = u16x8{o[half][0], o[half][1], o[half][2], o[half][3], o[half][4], o[half][5], o[half][6], o[half][7]};
+                else
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (row + u < g.M) p[u] = o[half][u];
+            }
+        }
+    }
+}
+
+// FAMILY only names the instantiation (one symbol per shape class of the fit), so that a profiler's per-kernel
+// summary separates them the way the in-library timer does; the code is identical.
+enum { FAM_GRAM, FAM_SMALL, FAM_APPLY, FAM_SKETCH, FAM_BIG, FAM_RESIDUAL, FAM_COUNT };
+template <int FAMILY, int FM, int FN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int BM = 32 * FM, BN = 32 * FN;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    // buffer b: A tile at smem + b * (BM + BN) * LDS_STRIDE, B tile right after it
+    auto As = [&](int b) { return smem + b * (BM + BN) * LDS_STRIDE; };
+    auto Bs = [&](int b) { return smem + b * (BM + BN) * LDS_STRIDE + BM * LDS_STRIDE; };
+
+    int row0, col0;
+    gemm_tile_origin<BM, BN>(g, row0, col0);
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u16x8 ra[4], rb[4];
+    gemm_stamp(g, 0);
+    u16x8 ra[BM / 32], rb[BN / 32];
     const int nk_total = (g.Kd + BK - 1) / BK;
     const int kt0 = g.splits > 1 ? (int)blockIdx.y * g.ksteps_per_split : 0;
     const int nk = g.splits > 1 ? min(g.ksteps_per_split, nk_total - kt0) : nk_total;
-    load_tile(g.A, g.lda, g.M, g.Kd, row0, kt0 * BK, ra);
-    load_tile(g.B, g.ldb, g.N, g.Kd, col0, kt0 * BK, rb);
-    store_tile(As(0), ra);
-    store_tile(Bs(0), rb);
+    load_tile<BM>(g.A, g.lda, g.M, g.Kd, row0, kt0 * BK, ra);
+    load_tile<BN>(g.B, g.ldb, g.N, g.Kd, col0, kt0 * BK, rb);
+    store_tile<BM>(As(0), ra);
+    store_tile<BN>(Bs(0), rb);
     __syncthreads();
+    gemm_stamp(g, 1);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile(g.A, g.lda, g.M, g.Kd, row0, (kt0 + kt + 1) * BK, ra);
-            load_tile(g.B, g.ldb, g.N, g.Kd, col0, (kt0 + kt + 1) * BK, rb);
+            load_tile<BM>(g.A, g.lda, g.M, g.Kd, row0, (kt0 + kt + 1) * BK, ra);
+            load_tile<BN>(g.B, g.ldb, g.N, g.Kd, col0, (kt0 + kt + 1) * BK, rb);
         }
-        const bf16_t* a_base = As(cur) + (wr * 64 + fr) * LDS_STRIDE + fq * 8;
-        const bf16_t* b_base = Bs(cur) + (wc * 64 + fr) * LDS_STRIDE + fq * 8;
+        const bf16_t* a_base = As(cur) + (wr * 16 * FM + fr) * LDS_STRIDE + fq * 8;
+        const bf16_t* b_base = Bs(cur) + (wc * 16 * FN + fr) * LDS_STRIDE + fq * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(a_base + i * 16 * LDS_STRIDE + ks * 32);
+            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(a_base + i * 16 * LDS_STRIDE + ks * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_base + j * 16 * LDS_STRIDE + ks * 32);
+            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(b_base + j * 16 * LDS_STRIDE + ks * 32);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            store_tile(As(cur ^ 1), ra);
-            store_tile(Bs(cur ^ 1), rb);
+            store_tile<BM>(As(cur ^ 1), ra);
+            store_tile<BN>(Bs(cur ^ 1), rb);
         }
         __syncthreads();
     }
+    gemm_stamp(g, 2);
+    gemm_epilogue<FM, FN>(g, acc, (float*)smem, row0, col0, wr, wc, fr, fq);
+    gemm_stamp(g, 3);
+}
 
-    // epilogue: fragment (i, j): rows row0 + wr*64 + i*16 + fq*4 + reg, column col0 + wc*64 + j*16 + fr
+// ---- the same product with the operand tiles copied global -> LDS by LDS-DMA, NST stages deep -------------------------
+// A workgroup's K-loop is bound by load latency (operands come from HBM / Infinity Cache, a microsecond away, while a
+// K-step of MFMAs takes a fifth of that), so what counts is how many K-steps of operands are in flight.  LDS-DMA loads
+// (global_load_lds) need no staging registers: NST LDS buffers hold NST - 1 tiles in flight while one is consumed.
+// The LDS image of a tile is written linearly by the DMA (64 lanes x 16 bytes per instruction), so the bank-conflict
+// swizzle is applied to the per-lane SOURCE address and again when the fragments are read: row r keeps its 16-byte
+// chunk c at slot c ^ swz(r).  Chunks beyond Kd are fetched from a 16-byte block of zeros.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef const __attribute__((address_space(1))) void global_cvoid;
+__device__ __attribute__((aligned(16))) bf16_t g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <int BKT>
+__device__ __forceinline__ int swz(int r) {
+    constexpr int SP = BKT / 8;             // 16-byte slots per row: 8 (BK 64) or 4 (BK 32)
+    return (r / (16 / SP)) % SP;            // rows r .. r + 15 at one chunk then cover all 64 banks once
+}
+
+template <int ROWS, int BKT>
+__device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
+                                          bf16_t* lds_tile) {
+    constexpr int SP = BKT / 8, RPI = 64 / SP, NI = ROWS / RPI / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = col0 + wc * 64 + j * 16 + fr;
-            const int rbase = row0 + wr * 64 + i * 16 + fq * 4;
-            if (col >= g.N) continue;
-            if (g.splits > 1) {
-                float* sl = g.slab + (int64_t)blockIdx.y * g.M * g.N;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rbase + r < g.M) sl[(int64_t)(rbase + r) * g.N + col] = acc[i][j][r];
-                continue;
-            }
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] * g.alpha;
-                if (g.beta != 0.f && rbase + r < g.M) v[r] += g.beta * g.C32[(int64_t)(rbase + r) * g.ldc32 + col];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rbase + r;
-                if (row >= g.M) continue;
-                if (g.C32) g.C32[(int64_t)row * g.ldc32 + col] = v[r];
-                if (g.C16) g.C16[(int64_t)row * g.ldc16 + col] = f32_to_bf16(v[r]);
-                if (g.Wn) {
-                    const int64_t o = (int64_t)row * g.ldw + col;
-                    const float lr = round_bf16(v[r]);
-                    g.Wn[o] = (g.mask && g.mask[o]) ? (bf16_t)0 : f32_to_bf16(bf16_to_f32(g.W[o]) - lr);
-                }
-            }
-            if (g.Ct16) {
-                bf16_t* p = g.Ct16 + (int64_t)col * g.ldct + rbase;
-                if (rbase + 3 < g.M && (g.ldct & 3) == 0) {
-                    u16x4 o = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-                    *(u16x4*)p = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rbase + r < g.M) p[r] = f32_to_bf16(v[r]);
-                }
-            }
-        }
+    for (int i = 0; i < NI; ++i) {
+        const int inst = wave * NI + i;                  // 1 KiB piece of the tile image
+        const int r = inst * RPI + lane / SP;
+        const int chunk = (lane % SP) ^ swz<BKT>(r);
+        int grow = row0 + r;
+        grow = grow < rows ? grow : rows - 1;
+        const int k = k0 + chunk * 8;
+        const bf16_t* src = k < Kd ? P + (int64_t)grow * ld + k : g_zero_chunk;
+        __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_u32*)(uintptr_t)(lds_tile + inst * 512), 16, 0, 0);
     }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int FAMILY, int FM, int FN, int BKT, int NST>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
+    constexpr int BM = 32 * FM, BN = 32 * FN;
+    constexpr int STAGE = (BM + BN) * BKT;                               // elements per stage
+    constexpr int LOADS = (BM + BN) / (64 / (BKT / 8)) / 4;              // LDS-DMA instructions per wave per stage
+    static_assert((NST - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    int row0, col0;
+    gemm_tile_origin<BM, BN>(g, row0, col0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gemm_stamp(g, 0);
+    const int nk_total = (g.Kd + BKT - 1) / BKT;
+    const int per_split = g.ksteps_per_split * (BK / BKT);               // the plan counts 64-deep steps
+    const int kt0 = g.splits > 1 ? (int)blockIdx.y * per_split : 0;
+    const int nk = g.splits > 1 ? min(per_split, nk_total - kt0) : nk_total;
+    // every stage issues the same number of loads per wave, also past the end of the reduction (those read the zero
+    // block), so that the counted waits below always mean "all but the newest NST - 2 stages have landed"
+    auto issue = [&](int kt) {
+        bf16_t* buf = smem + (kt % NST) * STAGE;
+        const int k0 = kt < nk ? (kt0 + kt) * BKT : g.Kd;
+        glds_tile<BM, BKT>(g.A, g.lda, g.M, g.Kd, row0, k0, buf);
+        glds_tile<BN, BKT>(g.B, g.ldb, g.N, g.Kd, col0, k0, buf + BM * BKT);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s);
+    wait_vm_lgkm0<(NST - 2) * LOADS>();
+    __builtin_amdgcn_s_barrier();
+    gemm_stamp(g, 1);
+
+    // fragment rows of this lane and their swizzles do not change over the loop
+    int a_off[FM], b_off[FN], a_sw[FM], b_sw[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int r = wr * 16 * FM + i * 16 + fr;
+        a_off[i] = r * BKT;
+        a_sw[i] = swz<BKT>(r);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int r = wc * 16 * FN + j * 16 + fr;
+        b_off[j] = BM * BKT + r * BKT;
+        b_sw[j] = swz<BKT>(r);
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // the buffer refilled here was read in the previous iteration; every wave has passed that iteration's barrier
+        // with its LDS reads retired
+        issue(kt + NST - 1);
+        const bf16_t* buf = smem + (kt % NST) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 32; ++ks) {
+            bf16x8 af[FM], bfr[FN];
+            const int c = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(buf + a_off[i] + ((c ^ a_sw[i]) << 3));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(buf + b_off[j] + ((c ^ b_sw[j]) << 3));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        // own share of stage kt + 1 has landed and own reads of stage kt are retired; after the barrier that holds
+        // for every wave
+        wait_vm_lgkm0<(NST - 2) * LOADS>();
+        __builtin_amdgcn_s_barrier();
+    }
+    // the dummy stages issued past the end still target LDS: let them land before the workgroup retires
+    wait_vm_lgkm0<0>();
+    gemm_stamp(g, 2);
+    gemm_epilogue<FM, FN>(g, acc, (float*)smem, row0, col0, wr, wc, fr, fq);
+    gemm_stamp(g, 3);
 }
 
 // C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order
@@ -201,18 +488,67 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     if (C16) C16[row * ldc16 + col] = f32_to_bf16(v);
 }
 
-int slim_gemm_launch(const GemmArgs& g, void* stream) {
+typedef void (*gemm_kernel_t)(GemmArgs);
+template <int FAMILY>
+static gemm_kernel_t gemm_kernel_of(int tile) {
+    switch (tile) {
+        case TILE_128x64: return gemm_nt_kernel<FAMILY, 4, 2>;
+        case TILE_64x128: return gemm_nt_kernel<FAMILY, 2, 4>;
+        case TILE_64x64: return gemm_nt_kernel<FAMILY, 2, 2>;
+        case DMA_128x128_S3: return gemm_nt_glds_kernel<FAMILY, 4, 4, 64, 3>;
+        case DMA_128x64_S3: return gemm_nt_glds_kernel<FAMILY, 4, 2, 64, 3>;
+        case DMA_64x128_S3: return gemm_nt_glds_kernel<FAMILY, 2, 4, 64, 3>;
+        case DMA_64x64_S4: return gemm_nt_glds_kernel<FAMILY, 2, 2, 64, 4>;
+        case DMA_128x128_K32_S6: return gemm_nt_glds_kernel<FAMILY, 4, 4, 32, 6>;
+        case DMA_64x64_K32_S6: return gemm_nt_glds_kernel<FAMILY, 2, 2, 32, 6>;
+        case DMA_128x128_S4: return gemm_nt_glds_kernel<FAMILY, 4, 4, 64, 4>;
+        default: return gemm_nt_kernel<FAMILY, 4, 4>;
+    }
+}
+
+// tile shape forced for every launch (-1: chosen per problem); a tuning aid, see slim_gemm_set_tile
+static int g_tile_override = -1;
+extern "C" void slim_gemm_set_tile(int tile) { g_tile_override = (tile >= 0 && tile < TILE_COUNT) ? tile : -1; }
+
+static int64_t* g_trace_buf = nullptr;
+static int g_trace_cap = 0;
+extern "C" void slim_gemm_set_trace(void* buf, int capacity_workgroups) {
+    g_trace_buf = (int64_t*)buf;
+    g_trace_cap = buf ? capacity_workgroups : 0;
+}
+
+// Tile choice.  Alone on the chip a small product finishes sooner with small tiles (a workgroup's K-loop is
+// latency-bound, so more workgroups mean more loads in flight), but the fit runs several linears' chains on
+// concurrent streams, where what counts is how long a product holds CU slots: there the 128 x 128 register-staged
+// tile is the cheapest for every shape class of the fit (measured on the whole compression step), so it is the default
+// and the other variants are reached through slim_gemm_set_tile.
+static int gemm_pick_tile(const GemmArgs& g, int batch) {
+    (void)g;
+    (void)batch;
+    return g_tile_override >= 0 ? g_tile_override : TILE_128x128;
+}
+
+int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
+    GemmArgs g = g_in;
+    g.trace = g_trace_buf;
+    g.trace_cap = g_trace_cap;
     SLIM_REQUIRE(g.A && g.B && g.M > 0 && g.N > 0 && g.Kd > 0, "slim_gemm_nt_bf16: bad arguments");
     SLIM_REQUIRE(g.Kd % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.lda >= g.Kd && g.ldb >= g.Kd,
                  "slim_gemm_nt_bf16: Kd, lda, ldb must be multiples of 8 and ld >= Kd");
     SLIM_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "slim_gemm_nt_bf16: operands must be 16-byte aligned");
     SLIM_REQUIRE(g.C32 || g.C16 || g.Ct16 || g.Wn, "slim_gemm_nt_bf16: no output requested");
-    SLIM_REQUIRE(!g.Ct16 || ((uintptr_t)g.Ct16 % 8) == 0, "slim_gemm_nt_bf16: Ct must be 8-byte aligned");
-    const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
+    SLIM_REQUIRE(!g.Ct16 || (((uintptr_t)g.Ct16 % 8) == 0 && g.beta == 0.f),
+                 "slim_gemm_nt_bf16: Ct must be 8-byte aligned and cannot be combined with beta");
     const int batch = g.batch > 1 ? g.batch : 1;
     SLIM_REQUIRE(batch <= 65535 && (batch == 1 || (!g.Wn && g.beta == 0.f)), "slim_gemm_nt_bf16: bad batch arguments");
-    const int lds_bytes = 4 * BM * LDS_STRIDE * (int)sizeof(bf16_t);
+    const int tile = gemm_pick_tile(g, batch);
+    const int BM = kTileM[tile], BN = kTileN[tile];
+    const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
+    const int loop_bytes = kTileStages[tile] ? kTileStages[tile] * (BM + BN) * kTileBK[tile] * (int)sizeof(bf16_t)
+                                             : 2 * (BM + BN) * LDS_STRIDE * (int)sizeof(bf16_t);
+    const int epilogue_bytes = BM * (BN + 1) * (int)sizeof(float);       // the output tile staged as fp32
+    const int lds_bytes = loop_bytes > epilogue_bytes ? loop_bytes : epilogue_bytes;
     const int mx = g.M > g.N ? g.M : g.N, mn = g.M < g.N ? g.M : g.N;
     const int fam = g.Wn ? FAM_RESIDUAL
                     : (mx <= 1536 && g.Kd > 1536) ? FAM_GRAM       // small output, long reduction
@@ -222,10 +558,15 @@ int slim_gemm_launch(const GemmArgs& g, void* stream) {
                     : FAM_BIG;
     static const char* const names[FAM_COUNT] = {"gemm_nt_gram", "gemm_nt_small", "gemm_nt_apply", "gemm_nt_sketch",
                                                  "gemm_nt_big", "gemm_nt_residual"};
-    typedef void (*kernel_t)(GemmArgs);
-    static const kernel_t kernels[FAM_COUNT] = {gemm_nt_kernel<FAM_GRAM>, gemm_nt_kernel<FAM_SMALL>, gemm_nt_kernel<FAM_APPLY>,
-                                                gemm_nt_kernel<FAM_SKETCH>, gemm_nt_kernel<FAM_BIG>, gemm_nt_kernel<FAM_RESIDUAL>};
-    const kernel_t kernel = kernels[fam];
+    gemm_kernel_t kernel = nullptr;
+    switch (fam) {
+        case FAM_GRAM: kernel = gemm_kernel_of<FAM_GRAM>(tile); break;
+        case FAM_SMALL: kernel = gemm_kernel_of<FAM_SMALL>(tile); break;
+        case FAM_APPLY: kernel = gemm_kernel_of<FAM_APPLY>(tile); break;
+        case FAM_SKETCH: kernel = gemm_kernel_of<FAM_SKETCH>(tile); break;
+        case FAM_BIG: kernel = gemm_kernel_of<FAM_BIG>(tile); break;
+        default: kernel = gemm_kernel_of<FAM_RESIDUAL>(tile); break;
+    }
     SLIM_HIP(slim_allow_dynamic_lds((const void*)kernel, lds_bytes));
     const char* scope = names[fam];
     SLIM_PROF(scope, stream,

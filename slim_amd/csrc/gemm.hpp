@@ -29,6 +29,10 @@ struct GemmArgs {
     // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
     int batch = 1;
     int64_t sA = 0, sB = 0, sC32 = 0, sC16 = 0, sCt = 0, sSlab = 0;
+    // tuning aid (slim_gemm_set_trace): when set, workgroup w < trace_cap stores 100 MHz timestamps at
+    // trace[8 w ..]: kernel entry, first tile staged, K-loop done, epilogue done
+    int64_t* trace = nullptr;
+    int trace_cap = 0;
 };
 
 // Launch (and, for splits > 1, reduce).  Split-K callers fill splits / ksteps_per_split through

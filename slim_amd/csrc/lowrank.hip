@@ -14,41 +14,14 @@
 #include "common.hpp"
 #include "../../include/slim_hip.h"
 #include "gemm.hpp"
+#include "solver.hpp"
+#include "eigh.hpp"
 #include <dlfcn.h>
-#include <mutex>
-#include <map>
-#include <utility>
 
 // ---- rocSOLVER / rocBLAS entry points, resolved at first use ---------------------------------
-// (values of the rocBLAS enums are part of its stable C ABI)
-namespace {
-typedef void* rb_handle;
-enum { RB_FILL_UPPER = 121, RB_FILL_LOWER = 122, RB_DIAG_NON_UNIT = 131, RB_EVECT_ORIGINAL = 211 };
-typedef int (*fn_create)(rb_handle*);
-typedef int (*fn_set_stream)(rb_handle, hipStream_t);
-typedef int (*fn_potrf)(rb_handle, int, int, float*, int, int*);
-typedef int (*fn_trtri)(rb_handle, int, int, int, float*, int, int*);
-typedef int (*fn_syevd)(rb_handle, int, int, int, float*, int, float*, float*, int*);
-typedef int (*fn_potrf_sb)(rb_handle, int, int, float*, int, int64_t, int*, int);
-typedef int (*fn_trtri_sb)(rb_handle, int, int, int, float*, int, int64_t, int*, int);
-typedef int (*fn_syevd_sb)(rb_handle, int, int, int, float*, int, int64_t, float*, int64_t, float*, int64_t, int*, int);
-
-struct Solver {
-    bool ok = false;
-    fn_create create = nullptr;
-    fn_set_stream set_stream = nullptr;
-    fn_potrf potrf = nullptr;
-    fn_trtri trtri = nullptr;
-    fn_syevd syevd = nullptr;
-    fn_potrf_sb potrf_sb = nullptr;      // strided-batched variants: one launch chain for a whole batch
-    fn_trtri_sb trtri_sb = nullptr;
-    fn_syevd_sb syevd_sb = nullptr;
-    std::map<std::pair<int, hipStream_t>, rb_handle> handles;  // per (device, stream): rocSOLVER keeps device workspace in the handle
-    std::mutex mu;
-};
 Solver g_solver;
 
-int solver_init() {
+static int solver_init() {
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
@@ -62,6 +35,8 @@ int solver_init() {
         g_solver.potrf_sb = (fn_potrf_sb)dlsym(h, "rocsolver_spotrf_strided_batched");
         g_solver.trtri_sb = (fn_trtri_sb)dlsym(h, "rocsolver_strtri_strided_batched");
         g_solver.syevd_sb = (fn_syevd_sb)dlsym(h, "rocsolver_ssyevd_strided_batched");
+        g_solver.stedc = (fn_stedc)dlsym(h, "rocsolver_sstedc");
+        g_solver.sgemm = (fn_sgemm)dlsym(h, "rocblas_sgemm");
         g_solver.ok = g_solver.create && g_solver.set_stream && g_solver.potrf && g_solver.trtri && g_solver.syevd;
     });
     if (!g_solver.ok) {
@@ -94,7 +69,6 @@ int solver_handle(hipStream_t st, rb_handle* out) {
     *out = it->second;
     return SLIM_OK;
 }
-}  // namespace
 
 // ---- small kernels -----------------------------------------------------------------------------
 // Every kernel below works on a strided batch of identical problems: the last grid dimension in use selects
@@ -560,23 +534,30 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     // Rayleigh-Ritz: B = Q^T E (kept as B^T = Z [K, l]); M = B B^T = W diag(S^2) W^T
     CHK(sketch_cols(w.A[a].Xt));
     CHK(gram(w.B[0].Xt, K, l, w, nullptr, stream));
-    int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l * batch) : -1;
-    if (batch > 1 && g_solver.syevd_sb) {
-        if (g_solver.syevd_sb(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, sG, w.evals, l, w.ework, l, w.info_tmp, batch) != 0) {
-            slim_set_error("rocsolver_ssyevd_strided_batched failed");
-            return SLIM_ERR_SOLVER;
-        }
-        CHK(scatter_info(w, ninfo, st));
+    if (!(flags & SLIM_FIT_LIBRARY_EIGH) && slim_eigh_supported(l) &&
+        slim_eigh_ws_bytes(l, batch) <= (int64_t)GRAM_MAX_SPLITS * l * l * 4 * batch) {
+        // in-library solver (one launch per column); the split-K slab is free at this point and serves as its workspace
+        CHK(slim_eigh_launch(w.G, l, batch, r, w.evals, w.info + ninfo, SLIM_FIT_INFO_WORDS, w.slab,
+                             (int64_t)GRAM_MAX_SPLITS * l * l * 4 * batch, st));
     } else {
-        for (int bi = 0; bi < batch; ++bi)
-            if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G + bi * sG, l, w.evals + (int64_t)bi * l,
-                               w.ework + (int64_t)bi * l, w.info + bi * SLIM_FIT_INFO_WORDS + ninfo) != 0) {
-                slim_set_error("rocsolver_ssyevd failed");
+        int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l * batch) : -1;
+        if (batch > 1 && g_solver.syevd_sb) {
+            if (g_solver.syevd_sb(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, sG, w.evals, l, w.ework, l, w.info_tmp, batch) != 0) {
+                slim_set_error("rocsolver_ssyevd_strided_batched failed");
                 return SLIM_ERR_SOLVER;
             }
+            CHK(scatter_info(w, ninfo, st));
+        } else {
+            for (int bi = 0; bi < batch; ++bi)
+                if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G + bi * sG, l, w.evals + (int64_t)bi * l,
+                                   w.ework + (int64_t)bi * l, w.info + bi * SLIM_FIT_INFO_WORDS + ninfo) != 0) {
+                    slim_set_error("rocsolver_ssyevd failed");
+                    return SLIM_ERR_SOLVER;
+                }
+        }
+        if (syevd_tok >= 0) slim_prof_end(syevd_tok, st);
     }
     ninfo += 1;
-    if (syevd_tok >= 0) slim_prof_end(syevd_tok, st);
     {
         dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
         top_eigvecs_kernel<<<grid, 256, 0, st>>>(w.G, w.evals, l, r, w.T16, S);

@@ -265,6 +265,21 @@ def gemm_nt_splitk(A, Bt, splits, alpha=1.0):
     return C32, C16
 
 
+def eigh(G, top=None):
+    """(evals ascending [n], vecs [n, n]) of the symmetric fp32 matrix G; row n-1-i of vecs is the eigenvector of the
+    i-th largest eigenvalue for i < top (default: all rows), the other rows hold no result."""
+    G = _chk(G, torch.float32, "G").clone()
+    n = G.shape[0]
+    if G.dim() != 2 or G.shape[1] != n:
+        raise ValueError("G must be square")
+    top = n if top is None else int(top)
+    evals = torch.empty(n, dtype=torch.float32, device=G.device)
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    ws = _ws(_lib.query("slim_eigh_workspace_bytes", n), G.device)
+    _lib.call("slim_eigh_f32", _p(G), n, top, _p(evals), _p(info), _p(ws), ws.numel(), _stream())
+    return evals, G, info
+
+
 def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
     """(Q [rows, l], Qt [l, rows], info): orthonormal basis of the column space of X [rows, l]."""
     X = _chk(X, BF16, "X")
@@ -278,7 +293,8 @@ def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
     return Q, Qt, info
 
 
-def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0, one_sided=False):
+def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0, one_sided=False,
+                library_eigh=False):
     """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info).
     E [B, N, K] (with Et [B, K, N], s [B, K]) runs B fits of identical shape in lockstep and returns
     tensors with a leading batch dimension."""
@@ -305,7 +321,7 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False,
     S = torch.empty(*lead, r, dtype=torch.float32, device=dev)
     info = torch.empty(*lead, 64, dtype=torch.int32, device=dev)
     ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", B, N, K, l), dev)
-    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)) | (2 if one_sided else 0),
+    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)) | (2 if one_sided else 0) | (4 if library_eigh else 0),
               int(ns_steps), _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 

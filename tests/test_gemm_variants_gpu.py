@@ -1,0 +1,43 @@
+"""Every workgroup-tile variant of the NT bf16 GEMM (register-staged and LDS-DMA pipelined) against a float64 product of
+the same bf16 operands, on full, ragged and tiny shapes, with every output form (fp32, bf16, transposed bf16, split-K)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_VARIANTS = 11
+SHAPES = [(128, 128, 64), (256, 384, 640), (200, 136, 72), (8, 8, 8), (640, 640, 520), (1000, 72, 1096), (64, 4096, 264),
+          (130, 258, 2056)]
+
+
+@pytest.fixture(autouse=True)
+def _reset_tile():
+    from slim_amd import _lib
+    yield
+    _lib.query("slim_gemm_set_tile", -1)
+
+
+@pytest.mark.parametrize("variant", list(range(N_VARIANTS)) + [-1])
+def test_gemm_variant_matches_reference(variant):
+    from slim_amd import _lib, ops
+    _lib.query("slim_gemm_set_tile", variant)
+    g = torch.Generator(device="cuda").manual_seed(variant + 5)
+    for M, N, Kd in SHAPES:
+        A = torch.randn(M, Kd, device="cuda", generator=g).to(torch.bfloat16)
+        Bt = torch.randn(N, Kd, device="cuda", generator=g).to(torch.bfloat16)
+        ref = A.double() @ Bt.double().t()
+        C32, C16, Ct = ops.gemm_nt(A, Bt, alpha=0.5, out_f32=True, out_bf16=True, out_t=True)
+        torch.cuda.synchronize()
+        tol = 2e-6 * Kd ** 0.5 * 4 + 1e-6
+        assert (C32.double() - 0.5 * ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (variant, M, N, Kd)
+        assert torch.equal(C16, C32.to(torch.bfloat16)), (variant, M, N, Kd)
+        assert torch.equal(Ct, C16.t()), (variant, M, N, Kd)
+        # accumulate into an existing fp32 matrix
+        C0 = torch.randn(M, N, device="cuda", generator=g)
+        out = ops.gemm_nt(A, Bt, alpha=1.0, beta=2.0, C32=C0.clone(), out_f32=True)
+        out = out[0] if isinstance(out, (tuple, list)) else out
+        assert (out.double() - (ref + 2.0 * C0.double())).abs().max().item() <= tol * max(1.0, ref.abs().max().item()) * 2
+        if Kd >= 256:
+            S32, S16 = ops.gemm_nt_splitk(A, Bt, splits=3)
+            assert (S32.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (variant, M, N, Kd, "split")
+            assert torch.equal(S16, S32.to(torch.bfloat16))
