@@ -166,6 +166,10 @@ void slim_gemm_set_trace(void* buf, int capacity_workgroups);
  * Rayleigh-Ritz step of slim_lowrank_fit (the part of torch.svd at slim/lora.py:172 that remains after the
  * subspace iteration): Householder tridiagonalisation with one launch per column, rocSOLVER stedc, one GEMM. */
 int64_t slim_eigh_workspace_bytes(int n);
+/* The first stage alone (no library call): Householder reduction Q^T A Q = tridiag(d, e) of a symmetric fp32 matrix
+ * A [n, n] (destroyed), one launch per column; Q [n, n] row-major, e holds n - 1 values, workspace of 5 n floats. */
+int slim_tridiagonalize_f32(float* A, int n, float* d, float* e, float* Q, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 int slim_eigh_f32(float* G, int n, int top, float* evals, int32_t* info, void* workspace, int64_t workspace_bytes,
                   void* stream);
 

@@ -15,14 +15,15 @@ hipError_t slim_allow_dynamic_lds(const void* func, int bytes);
 
 // Optional per-launch timing (slim_profile_enable): an RAII scope records a HIP event pair on the
 // launch stream around the kernels it encloses.
-int slim_prof_begin(const char* name, hipStream_t st, double bytes = 0.0, double flops = 0.0);
+// launches: how many kernel launches the scope encloses (a chain of identical launches is reported per launch)
+int slim_prof_begin(const char* name, hipStream_t st, double bytes = 0.0, double flops = 0.0, int launches = 1);
 void slim_prof_end(int token, hipStream_t st);
 extern bool g_slim_prof_on;
 struct SlimProfScope {
     int token;
     hipStream_t st;
-    SlimProfScope(const char* name, hipStream_t s, double bytes = 0.0, double flops = 0.0)
-        : token(g_slim_prof_on ? slim_prof_begin(name, s, bytes, flops) : -1), st(s) {}
+    SlimProfScope(const char* name, hipStream_t s, double bytes = 0.0, double flops = 0.0, int launches = 1)
+        : token(g_slim_prof_on ? slim_prof_begin(name, s, bytes, flops, launches) : -1), st(s) {}
     ~SlimProfScope() {
         if (token >= 0) slim_prof_end(token, st);
     }

@@ -33,9 +33,47 @@ struct TridiagArgs {
     int n, j;
 };
 
+// Wave-wide sums on the data-parallel-primitive path (cross-lane moves inside the VALU, a few cycles each) instead of
+// ds_bpermute shuffles (an LDS round trip each): the kernel below is a chain of four dependent reductions and is
+// latency-bound, so the shuffles alone were a third of its run time.  After the four steps every lane of a 16-lane
+// row holds the row's sum; the four row sums are combined through scalar lane reads.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    v += dpp_f<0x140>(v);     // row_mirror
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_d(double x, int lane) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_fast_d(double v) {
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    return lane_d(v, 0) + lane_d(v, 16) + lane_d(v, 32) + lane_d(v, 48);
+}
+
+// sum over the 256 threads; `red` must be a slot of four doubles that no earlier call in the kernel used
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
-    v = wave_sum_d(v);
-    __syncthreads();     // protects `red` against the previous use
+    v = wave_sum_fast_d(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
@@ -45,8 +83,9 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 template <int MAXV>
 __global__ __launch_bounds__(TD_THREADS) void tridiag_step_kernel(TridiagArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ double red[4];
+    __shared__ double red[8];
     const int n = g.n, j = g.j, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
     {
         const int64_t bz = blockIdx.y;
         g.A += bz * n * n;
@@ -61,125 +100,162 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_step_kernel(TridiagArgs g)
     float* wp = sm + n;        // its w
     float* v = sm + 2 * n;     // this column's reflector (zero up to and including j)
 
-    // (1) finish reflector j-1
-    if (j > 0) {
-        const float tau_p = g.taus[j - 1];
+    // Everything this workgroup reads from memory was written by the previous launch on other CUs, so each read is a
+    // trip to the memory side of the chip (a microsecond).  All of them are issued here, before the first barrier:
+    // the previous reflector's vectors, row j, and the rows this wave will update.
+    const int nA = n - j - 1;                              // trailing rows j+1 .. n-1
+    const int mstart = (j + 1) / 256;
+    const int msq = j == 0 ? 0 : mstart;
+    int task_row[TD_ROWS_PER_WAVE];                        // >= 0: row of A; < 0: ~row of Q; INT_MIN: none
+    f32x4 rowv[TD_ROWS_PER_WAVE][MAXV];
+#pragma unroll
+    for (int rr = 0; rr < TD_ROWS_PER_WAVE; ++rr) {
+        const int task = ((int)blockIdx.x * (TD_THREADS / 64) + wave) * TD_ROWS_PER_WAVE + rr;
+        const bool isA = task < nA, isQ = !isA && task < nA + n;
+        const int i = isA ? j + 1 + task : task - nA;
+        task_row[rr] = isA ? i : (isQ ? ~i : (int)0x80000000);
+        const float* row = (isA ? g.A : g.Q) + (int64_t)i * n;
+#pragma unroll
+        for (int m = 0; m < MAXV; ++m) {
+            const int k = 256 * m + 4 * lane;
+            rowv[rr][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((isA && m >= mstart && k < n) || (isQ && j > 0 && m >= msq && k < n)) rowv[rr][m] = *(const f32x4*)(row + k);
+            if (isQ && j == 0 && k < n) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rowv[rr][m][c] = (k + c == i) ? 1.f : 0.f;
+            }
+        }
+    }
+    float pv[MAXV], pp[MAXV], px[MAXV];                    // strided shares of v', p' and row j (n <= 256 * MAXV)
+    const float tau_p = j > 0 ? g.taus[j - 1] : 0.f;
+    {
         const float* vg = g.vbuf + ((j - 1) & 1) * n;
         const float* pg = g.pbuf + ((j - 1) & 1) * n;
-        double dot = 0.0;
-        for (int k = j + t; k < n; k += TD_THREADS) {
-            const float vv = vg[k], pp = pg[k];
-            vp[k] = vv;
-            wp[k] = pp;
-            dot += (double)vv * (double)pp;
+        const float* rowj = g.A + (int64_t)j * n;
+#pragma unroll
+        for (int s = 0; s < MAXV; ++s) {
+            const int k = j + t + TD_THREADS * s;
+            pv[s] = pp[s] = px[s] = 0.f;
+            if (k < n) {
+                px[s] = rowj[k];
+                if (j > 0) {
+                    pv[s] = vg[k];
+                    pp[s] = pg[k];
+                }
+            }
         }
+    }
+
+    // (1) finish reflector j-1
+    if (j > 0) {
+        double dot = 0.0;
+#pragma unroll
+        for (int s = 0; s < MAXV; ++s) dot += (double)pv[s] * (double)pp[s];
         dot = block_sum_d(dot, red);
         const float alpha = -0.5f * tau_p * (float)dot;
-        for (int k = j + t; k < n; k += TD_THREADS) wp[k] += alpha * vp[k];
+#pragma unroll
+        for (int s = 0; s < MAXV; ++s) {
+            const int k = j + t + TD_THREADS * s;
+            if (k < n) {
+                vp[k] = pv[s];
+                wp[k] = pp[s] + alpha * pv[s];
+            }
+        }
         __syncthreads();
     }
 
     // (2) row j of the updated matrix -> d[j] and reflector j from its entries right of the diagonal
-    {
-        const float* rowj = g.A + (int64_t)j * n;
-        const float wj = j > 0 ? wp[j] : 0.f;
-        double nrm = 0.0;
-        for (int k = j + t; k < n; k += TD_THREADS) {
-            float x = rowj[k];
+    const float wj = j > 0 ? wp[j] : 0.f;
+    double nrm = 0.0;
+#pragma unroll
+    for (int s = 0; s < MAXV; ++s) {
+        const int k = j + t + TD_THREADS * s;
+        if (k < n) {
+            float x = px[s];
             if (j > 0) x -= wp[k] + wj * vp[k];      // v'[j] w'[k] + w'[j] v'[k] with v'[j] == 1
             v[k] = x;
             if (k >= j + 2) nrm += (double)x * (double)x;
         }
-        nrm = block_sum_d(nrm, red);                 // its barriers also publish v[]
-        const float dj = v[j], a1 = v[j + 1];
-        const float xnorm = (float)sqrt(nrm);
-        float beta, tau, scale;
-        if (xnorm == 0.f) {
-            tau = 0.f;
-            beta = a1;
-            scale = 0.f;
-        } else {
-            beta = -copysignf(hypotf(a1, xnorm), a1);
-            tau = (beta - a1) / beta;
-            scale = 1.f / (a1 - beta);
+    }
+    nrm = block_sum_d(nrm, red + 4);                 // its barrier also publishes v[]
+    const float dj = v[j], a1 = v[j + 1];
+    const float xnorm = (float)sqrt(nrm);
+    float beta, tau, scale;
+    if (xnorm == 0.f) {
+        tau = 0.f;
+        beta = a1;
+        scale = 0.f;
+    } else {
+        beta = -copysignf(hypotf(a1, xnorm), a1);
+        tau = (beta - a1) / beta;
+        scale = 1.f / (a1 - beta);
+    }
+    __syncthreads();                                 // every thread has read v[j], v[j + 1]
+    for (int k = j + t; k < n; k += TD_THREADS) v[k] = k <= j ? 0.f : (k == j + 1 ? 1.f : v[k] * scale);
+    for (int k = t; k < j; k += TD_THREADS) v[k] = 0.f;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        float* vg = g.vbuf + (j & 1) * n;
+        for (int k = j + 1 + t; k < n; k += TD_THREADS) vg[k] = v[k];
+        if (t == 0) {
+            g.taus[j] = tau;
+            g.d[j] = dj;
+            g.e[j] = beta;
         }
-        __syncthreads();                             // every thread has read v[j], v[j + 1]
-        for (int k = j + t; k < n; k += TD_THREADS) v[k] = k <= j ? 0.f : (k == j + 1 ? 1.f : v[k] * scale);
-        for (int k = t; k < j; k += TD_THREADS) v[k] = 0.f;
-        __syncthreads();
-        if (blockIdx.x == 0) {
-            float* vg = g.vbuf + (j & 1) * n;
-            for (int k = j + 1 + t; k < n; k += TD_THREADS) vg[k] = v[k];
-            if (t == 0) {
-                g.taus[j] = tau;
-                g.d[j] = dj;
-                g.e[j] = beta;
-            }
-        }
+    }
 
-        // (3) + (4): one row per wave at a time
-        const int lane = t & 63, wave = t >> 6;
-        const int nA = n - j - 1;                              // trailing rows j+1 .. n-1
-        const int nQ = (j == 0 || tau != 0.f) ? n : 0;         // Q is created at j == 0
-        const int mstart = (j + 1) / 256;
-        float* pg = g.pbuf + (j & 1) * n;
-#pragma unroll 1
-        for (int rr = 0; rr < TD_ROWS_PER_WAVE; ++rr) {
-            const int task = ((int)blockIdx.x * (TD_THREADS / 64) + wave) * TD_ROWS_PER_WAVE + rr;
-            if (task < nA) {
-                const int i = j + 1 + task;
-                float* row = g.A + (int64_t)i * n;
-                const float vi = j > 0 ? vp[i] : 0.f, wi = j > 0 ? wp[i] : 0.f;
-                float acc = 0.f;
+    // (3) + (4): one row per wave at a time, from the registers filled above
+    float* pg = g.pbuf + (j & 1) * n;
 #pragma unroll
-                for (int m = 0; m < MAXV; ++m) {
-                    const int k = 256 * m + 4 * lane;
-                    if (m < mstart || k >= n) continue;
-                    f32x4 a = *(const f32x4*)(row + k);
-                    const f32x4 vv = *(const f32x4*)(v + k);
-                    if (j > 0) {
-                        const f32x4 w4 = *(const f32x4*)(wp + k), v4 = *(const f32x4*)(vp + k);
+    for (int rr = 0; rr < TD_ROWS_PER_WAVE; ++rr) {
+        const int tr = task_row[rr];
+        if (tr == (int)0x80000000) continue;
+        if (tr >= 0) {
+            const int i = tr;
+            float* row = g.A + (int64_t)i * n;
+            const float vi = j > 0 ? vp[i] : 0.f, wi = j > 0 ? wp[i] : 0.f;
+            float acc = 0.f;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (k + c >= j + 1) a[c] -= vi * w4[c] + wi * v4[c];
-                        *(f32x4*)(row + k) = a;
-                    }
+            for (int m = 0; m < MAXV; ++m) {
+                const int k = 256 * m + 4 * lane;
+                if (m < mstart || k >= n) continue;
+                f32x4 a = rowv[rr][m];
+                const f32x4 vv = *(const f32x4*)(v + k);
+                if (j > 0) {
+                    const f32x4 w4 = *(const f32x4*)(wp + k), v4 = *(const f32x4*)(vp + k);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc += a[c] * vv[c];     // v is zero left of column j + 1
-                    if (i == n - 1 && k <= n - 1 && n - 1 < k + 4) g.d[n - 1] = a[(n - 1) - k];   // final once j == n - 2
+                    for (int c = 0; c < 4; ++c)
+                        if (k + c >= j + 1) a[c] -= vi * w4[c] + wi * v4[c];
+                    *(f32x4*)(row + k) = a;
                 }
-                acc = wave_sum(acc);
-                if (lane == 0) pg[i] = tau * acc;
-            } else if (task < nA + nQ) {
-                const int i = task - nA;
-                float* row = g.Q + (int64_t)i * n;
-                const int ms = j == 0 ? 0 : mstart;
-                f32x4 q[MAXV];
-                float acc = 0.f;
 #pragma unroll
-                for (int m = 0; m < MAXV; ++m) {
-                    const int k = 256 * m + 4 * lane;
-                    if (m < ms || k >= n) continue;
-                    if (j == 0) {
+                for (int c = 0; c < 4; ++c) acc += a[c] * vv[c];     // v is zero left of column j + 1
+                if (i == n - 1 && k <= n - 1 && n - 1 < k + 4) g.d[n - 1] = a[(n - 1) - k];   // final once j == n - 2
+            }
+            acc = wave_sum_fast(acc);
+            if (lane == 0) pg[i] = tau * acc;
+        } else if (j == 0 || tau != 0.f) {                 // Q is created at j == 0
+            const int i = ~tr;
+            float* row = g.Q + (int64_t)i * n;
+            float acc = 0.f;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) q[m][c] = (k + c == i) ? 1.f : 0.f;
-                    } else {
-                        q[m] = *(const f32x4*)(row + k);
-                    }
-                    const f32x4 vv = *(const f32x4*)(v + k);
+            for (int m = 0; m < MAXV; ++m) {
+                const int k = 256 * m + 4 * lane;
+                if (m < msq || k >= n) continue;
+                const f32x4 vv = *(const f32x4*)(v + k);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc += q[m][c] * vv[c];
-                }
-                const float s = tau * wave_sum(acc);
+                for (int c = 0; c < 4; ++c) acc += rowv[rr][m][c] * vv[c];
+            }
+            const float s = tau * wave_sum_fast(acc);
 #pragma unroll
-                for (int m = 0; m < MAXV; ++m) {
-                    const int k = 256 * m + 4 * lane;
-                    if (m < ms || k >= n) continue;
-                    const f32x4 vv = *(const f32x4*)(v + k);
+            for (int m = 0; m < MAXV; ++m) {
+                const int k = 256 * m + 4 * lane;
+                if (m < msq || k >= n) continue;
+                const f32x4 vv = *(const f32x4*)(v + k);
+                f32x4 q = rowv[rr][m];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) q[m][c] -= s * vv[c];
-                    *(f32x4*)(row + k) = q[m];
-                }
+                for (int c = 0; c < 4; ++c) q[c] -= s * vv[c];
+                *(f32x4*)(row + k) = q;
             }
         }
     }
@@ -228,6 +304,28 @@ static void launch_step(const TridiagArgs& a, int batch, hipStream_t st) {
     hipLaunchKernelGGL(tridiag_step_kernel<MAXV>, grid, dim3(TD_THREADS), (size_t)3 * n * sizeof(float), st, a);
 }
 
+// Householder reduction Q^T A Q = T of `batch` symmetric matrices, one launch per column: d / e receive the diagonal and
+// off-diagonal of T, Q the accumulated reflectors (row-major); A is destroyed.
+static int tridiagonalize(float* A, float* Q, float* vbuf, float* pbuf, float* taus, float* d, float* e, int n, int batch,
+                          hipStream_t st) {
+    // algorithmic traffic: launch j reads and writes the trailing (n-j-1)^2 block of A and n x (n-j-1) of Q, fp32
+    double bytes = 0.0;
+    for (int j = 0; j <= n - 2; ++j) {
+        const double w = n - j - 1;
+        bytes += 8.0 * (w * w + (j == n - 2 ? 0.0 : (double)n * w));
+    }
+    SLIM_PROF("eigh_tridiag", st, bytes * batch, (4.0 / 3.0 + 2.0) * n * (double)n * n * batch, n - 1);
+    TridiagArgs a{A, Q, vbuf, pbuf, taus, d, e, n, 0};
+    for (int j = 0; j <= n - 2; ++j) {
+        a.j = j;
+        if (n <= 768) launch_step<3>(a, batch, st);
+        else if (n <= 1280) launch_step<5>(a, batch, st);
+        else launch_step<8>(a, batch, st);
+    }
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 int slim_eigh_launch(float* G, int n, int batch, int top, float* evals, int* info, int info_stride, void* ws,
                      int64_t ws_bytes, hipStream_t st) {
     SLIM_REQUIRE(G && evals && info && ws && batch >= 1 && batch <= 65535, "slim_eigh: bad arguments");
@@ -240,17 +338,8 @@ int slim_eigh_launch(float* G, int n, int batch, int top, float* evals, int* inf
     if (rc) return rc;
     SLIM_REQUIRE(g_solver.stedc && g_solver.sgemm, "slim_eigh: rocsolver_sstedc / rocblas_sgemm not available");
     EighWs w = eigh_ws((char*)ws, n, batch);
-    {
-        SLIM_PROF("eigh_tridiag", st, 0.0, (4.0 / 3.0 + 2.0) * n * (double)n * n * batch);
-        TridiagArgs a{G, w.Q, w.vbuf, w.pbuf, w.taus, evals, w.e, n, 0};
-        for (int j = 0; j <= n - 2; ++j) {
-            a.j = j;
-            if (n <= 768) launch_step<3>(a, batch, st);
-            else if (n <= 1280) launch_step<5>(a, batch, st);
-            else launch_step<8>(a, batch, st);
-        }
-        SLIM_LAUNCH_CHECK();
-    }
+    rc = tridiagonalize(G, w.Q, w.vbuf, w.pbuf, w.taus, evals, w.e, n, batch, st);
+    if (rc) return rc;
     {
         SLIM_PROF("solver_stedc", st, 0.0, 4.0 * n * (double)n * n * batch);
         for (int b = 0; b < batch; ++b)
@@ -274,6 +363,18 @@ int slim_eigh_launch(float* G, int n, int batch, int top, float* evals, int* inf
             }
     }
     return SLIM_OK;
+}
+
+// The reduction alone (no library call): A [n, n] symmetric fp32 (destroyed) -> d [n], e [n] (n - 1 used), Q [n, n]
+// row-major with Q^T A Q = tridiag(d, e).  workspace: 5 n floats.
+extern "C" int slim_tridiagonalize_f32(float* A, int n, float* d, float* e, float* Q, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+    SLIM_REQUIRE(A && d && e && Q && workspace, "slim_tridiagonalize_f32: null pointer");
+    SLIM_REQUIRE(n >= 3 && n <= SLIM_EIGH_MAX_N && n % 4 == 0, "slim_tridiagonalize_f32: n must be a multiple of 4 in [4, 2048]");
+    SLIM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)Q % 16) == 0, "slim_tridiagonalize_f32: buffers must be 16-byte aligned");
+    SLIM_REQUIRE(workspace_bytes >= (int64_t)5 * n * 4, "slim_tridiagonalize_f32: workspace too small");
+    float* ws = (float*)workspace;
+    return tridiagonalize(A, Q, ws, ws + 2 * n, ws + 4 * n, d, e, n, 1, (hipStream_t)stream);
 }
 
 extern "C" int64_t slim_eigh_workspace_bytes(int n) { return n > 0 ? slim_eigh_ws_bytes(n, 1) : 0; }

@@ -45,17 +45,19 @@ struct ProfRec {
     std::string name;
     hipEvent_t a, b;
     double bytes, flops;
+    int launches;
 };
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
 }  // namespace
 
-int slim_prof_begin(const char* name, hipStream_t st, double bytes, double flops) {
+int slim_prof_begin(const char* name, hipStream_t st, double bytes, double flops, int launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.name = name;
     r.bytes = bytes;
     r.flops = flops;
+    r.launches = launches > 0 ? launches : 1;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     (void)hipEventRecord(r.a, st);
     g_prof.push_back(r);
@@ -92,7 +94,7 @@ extern "C" int slim_profile_summary(char* buf, int64_t buflen) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
         auto& e = acc[r.name];
-        e.n += 1;
+        e.n += r.launches;
         e.ms += ms;
         e.bytes += r.bytes;
         e.flops += r.flops;

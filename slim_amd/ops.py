@@ -265,6 +265,20 @@ def gemm_nt_splitk(A, Bt, splits, alpha=1.0):
     return C32, C16
 
 
+def tridiagonalize(G):
+    """(d [n], e [n-1], Q [n, n]) with Q.T @ G @ Q = tridiag(d, e) for a symmetric fp32 matrix G."""
+    G = _chk(G, torch.float32, "G").clone()
+    n = G.shape[0]
+    if G.dim() != 2 or G.shape[1] != n:
+        raise ValueError("G must be square")
+    d = torch.empty(n, dtype=torch.float32, device=G.device)
+    e = torch.empty(n, dtype=torch.float32, device=G.device)
+    Q = torch.empty(n, n, dtype=torch.float32, device=G.device)
+    ws = torch.empty(5 * n, dtype=torch.float32, device=G.device)
+    _lib.call("slim_tridiagonalize_f32", _p(G), n, _p(d), _p(e), _p(Q), _p(ws), ws.numel() * 4, _stream())
+    return d, e[:n - 1], Q
+
+
 def eigh(G, top=None):
     """(evals ascending [n], vecs [n, n]) of the symmetric fp32 matrix G; row n-1-i of vecs is the eigenvector of the
     i-th largest eigenvalue for i < top (default: all rows), the other rows hold no result."""

@@ -52,6 +52,19 @@ def test_eigh_matches_numpy(n, kind):
     assert orth <= 2e-4, orth
 
 
+@pytest.mark.parametrize("n", [4, 64, 260, 640])
+def test_tridiagonalize_is_an_orthogonal_similarity(n):
+    from slim_amd import ops
+    rng = np.random.default_rng(n + 1)
+    A = rng.standard_normal((n, n))
+    A = ((A + A.T) / 2).astype(np.float32)
+    d, e, Q = (t.cpu().numpy().astype(np.float64) for t in ops.tridiagonalize(torch.from_numpy(A).cuda()))
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    scale = np.abs(A).max() * n ** 0.5
+    assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-5 * n ** 0.5
+    assert np.abs(Q.T @ A.astype(np.float64) @ Q - T).max() <= 2e-6 * scale * n ** 0.5
+
+
 def test_eigh_rejects_bad_arguments():
     from slim_amd import ops
     with pytest.raises(Exception):

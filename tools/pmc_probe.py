@@ -4,7 +4,8 @@
 Counter collection on the bench itself aborts inside rocSOLVER (SIGSEGV in the eigen-solver call under
 `rocprofv3 --pmc`), so this script issues the library's own kernels with the shapes and counts of a bench step --
 statistics (4 distinct inputs), mask, histograms, error matrix, transposes, and per linear the 13 sketch products and
-13 x 4 Newton-Schulz steps (Gram with the fit's split-K, l x l square, apply) on random operands, residual and
+13 x 4 Newton-Schulz steps (Gram with the fit's split-K, l x l square, apply) on random operands, the
+tridiagonalisation of an l x l matrix (the eigen-solver's own stage, without its rocSOLVER part), residual and
 re-quantisation -- everything from the main thread on one stream."""
 import os
 import sys
@@ -70,4 +71,10 @@ for rep in range(2):                 # the first pass warms code objects and the
         hist = ops.hist_abs(Wn)
         ops.fake_quant_pt(Wn, sf, 4)
     torch.cuda.synchronize()
-print("done")
+    print("pass", rep, "done", flush=True)
+# the Rayleigh-Ritz matrix's tridiagonalisation (first stage of the eigen-solver, no library call), once: counter
+# collection serialises every launch, and this stage is 639 of them
+Gs = torch.randn(L_DIM, 4 * L_DIM, device=dev)
+ops.tridiagonalize(Gs @ Gs.t())
+torch.cuda.synchronize()
+print("done", flush=True)
