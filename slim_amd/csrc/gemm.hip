@@ -436,6 +436,40 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
         b_sw[j] = swz<BKT>(r);
     }
 
+    if constexpr (BKT == 64) {
+        // All sixteen fragment reads of a K-step are issued at once, ahead of the DMA issue block and of the MFMAs: with
+        // one wave per SIMD nothing else hides the LDS latency, and taken in four read-wait-MFMA rounds (the order the
+        // compiler picks to save registers) it costs three times the MFMA time of the K-step.
+        bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+        auto read = [&](const bf16_t* buf, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+            const int c = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(buf + a_off[i] + ((c ^ a_sw[i]) << 3));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(buf + b_off[j] + ((c ^ b_sw[j]) << 3));
+        };
+        auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&bfr)[FN]) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
+        for (int kt = 0; kt < nk; ++kt) {
+            const bf16_t* buf = smem + (kt % NST) * STAGE;
+            read(buf, 0, a0, b0);
+            read(buf, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the buffer refilled here held stage kt-1, whose reads were retired before the previous barrier; the address
+            // arithmetic of the eight DMA issues runs while the sixteen LDS reads above are in flight
+            issue(kt + NST - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);                                  // needs only the first half of the reads
+            mma(a1, b1);
+            wait_vm_lgkm0<(NST - 2) * LOADS>();           // own share of stage kt+1 has landed
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
         // the buffer refilled here was read in the previous iteration; every wave has passed that iteration's barrier
         // with its LDS reads retired
@@ -459,6 +493,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
         // for every wave
         wait_vm_lgkm0<(NST - 2) * LOADS>();
         __builtin_amdgcn_s_barrier();
+    }
     }
     // the dummy stages issued past the end still target LDS: let them land before the workgroup retires
     wait_vm_lgkm0<0>();

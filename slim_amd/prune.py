@@ -8,6 +8,7 @@ per-linear step (statistics, mask, scale search, quantisation, low-rank fit) is 
 """
 import os
 import threading
+import time
 
 import torch
 import torch.nn as nn
@@ -67,6 +68,12 @@ def block_stats(wrapped_list):
         w.outliers, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx)
 
 
+# SLIM_STREAM_TRACE=1: run_on_streams records, per job, when its host thread started / finished enqueueing and when its
+# stream started / finished executing it (ms after the call), into LAST_STREAM_TRACE; costs a device sync per call
+STREAM_TRACE = os.environ.get("SLIM_STREAM_TRACE", "0") == "1"
+LAST_STREAM_TRACE = []
+
+
 def run_on_streams(jobs, dev, n_streams=None):
     """Run independent GPU jobs (callables that only enqueue work and return the tensors they produced) on side
     streams that start after the current stream's pending work; the current stream then waits for all of them.
@@ -82,9 +89,12 @@ def run_on_streams(jobs, dev, n_streams=None):
             job()
         return
     streams = _streams_for(dev, min(n, len(jobs)))
-    ev = torch.cuda.Event()
+    trace = STREAM_TRACE
+    ev = torch.cuda.Event(enable_timing=trace)
     ev.record(main)
     errors = []
+    t_base = time.perf_counter()
+    records = []
 
     def feed(si):
         try:
@@ -93,7 +103,14 @@ def run_on_streams(jobs, dev, n_streams=None):
             st.wait_event(ev)
             with torch.cuda.stream(st), torch.no_grad():
                 for idx in range(si, len(jobs), len(streams)):
+                    if trace:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(st)
+                        h0 = time.perf_counter()
                     produced = jobs[idx]() or ()
+                    if trace:
+                        e1.record(st)
+                        records.append((idx, si, h0 - t_base, time.perf_counter() - t_base, e0, e1))
                     for t in produced:          # these outlive the side stream's scope and are used on `main`
                         if isinstance(t, torch.Tensor) and t.is_cuda:
                             t.record_stream(main)
@@ -109,6 +126,11 @@ def run_on_streams(jobs, dev, n_streams=None):
         main.wait_stream(st)
     if errors:
         raise errors[0]
+    if trace:
+        torch.cuda.synchronize(dev)
+        LAST_STREAM_TRACE[:] = [dict(job=idx, stream=si, host_start_ms=h0 * 1e3, host_end_ms=h1 * 1e3,
+                                     gpu_start_ms=ev.elapsed_time(e0), gpu_end_ms=ev.elapsed_time(e1))
+                                for idx, si, h0, h1, e0, e1 in sorted(records)]
 
 
 def _device():
