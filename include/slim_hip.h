@@ -152,6 +152,15 @@ int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* Bt, int64_t
                              float alpha, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16, int splits,
                              float* slab, void* stream);
 
+/* Adapter pruning, the optimisation loop of prune_and_optimize_lora (slim/lora.py:28-50): num_iters Adam steps
+ * (torch defaults; lr decaying linearly to lr * lr_end_factor) on fp32 L [K, r] (zero where L_mask is set and kept so)
+ * and R [r, N] for || L R - T ||_F / || T ||_F, T [K, N] fp32.  Everything is enqueued on `stream`, nothing
+ * synchronises; losses (num_iters floats on the device, or NULL) receives the loss each iteration saw. */
+int64_t slim_lora_prune_workspace_bytes(int64_t K, int64_t r, int64_t N);
+int slim_lora_prune_optimize(float* L, float* R, const uint8_t* L_mask, const float* T, int64_t K, int64_t r, int64_t N,
+                             int num_iters, float lr, float lr_end_factor, float* losses, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* Tuning aid: force the workgroup tile of every following GEMM launch in this process (0: 128x128, 1: 128x64,
  * 2: 64x128, 3: 64x64; anything else: chosen per problem, the default).  Results do not depend on the tile. */
 void slim_gemm_set_tile(int tile);

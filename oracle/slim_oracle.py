@@ -289,6 +289,40 @@ def add_lora(W, W_mask, scaler_row, rank_ratio, num_bits=4, tile=None, slim_lora
                 rank=rank, singular_values=S)
 
 
+def prune_and_optimize_lora(L, R, num_iters=1000, lr_end_factor=1e-4, return_losses=False):
+    """slim/lora.py:7-53 without autograd: 2:4 mask over the SIGNED entries of L^T (prune_nm marks the two smallest
+    of every four along K, :27), then num_iters Adam steps (betas 0.9 / 0.999, eps 1e-8, lr = 1e6 / min(K, N)^2
+    decaying linearly to lr * lr_end_factor, :31-32) on fp32 copies of L [K, r] and R [r, N] for the loss
+    ||L R - target||_F / ||target||_F with target = float(bf16 L @ bf16 R) (:25), masked entries of L reset to zero
+    after every step (:41).  Returns (L bf16, R bf16, mask[, losses])."""
+    target = torch.matmul(L, R).float()
+    tnorm = torch.norm(target).item()
+    mask = prune_nm(L.t(), 2, 4).t()
+    L = L.clone()
+    L[mask] = 0
+    Lp, Rp = L.float(), R.float()
+    lr0 = 1e6 / min(L.shape[0], R.shape[1]) ** 2
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    mL, vL, mR, vR = (torch.zeros_like(t) for t in (Lp, Lp, Rp, Rp))
+    losses = []
+    for it in range(num_iters):
+        lr = lr0 * (1.0 + (lr_end_factor - 1.0) * min(it, num_iters) / num_iters)
+        D = torch.matmul(Lp, Rp) - target
+        nrm = torch.norm(D)
+        losses.append((nrm / tnorm).item())
+        G = D / (nrm * tnorm)                      # d loss / d (L R)
+        gL, gR = G @ Rp.t(), Lp.t() @ G
+        t = it + 1
+        for p_, g_, m_, v_ in ((Lp, gL, mL, vL), (Rp, gR, mR, vR)):
+            m_.mul_(b1).add_(g_, alpha=1 - b1)
+            v_.mul_(b2).addcmul_(g_, g_, value=1 - b2)
+            denom = (v_.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+            p_.addcdiv_(m_, denom, value=-lr / (1 - b1 ** t))
+        Lp[mask] = 0
+    out = (Lp.to(torch.bfloat16), Rp.to(torch.bfloat16), mask)
+    return out + (losses,) if return_losses else out
+
+
 # --------------------------------------------------------------------------------------
 # Input quantisation hooks
 # --------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "slim_error_matrix_deq": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp]),
     "slim_transpose_bf16": (i32, [vp, i64, i64, vp, vp]),
     "slim_gemm_nt_bf16": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, f32, vp, i64, vp, i64, vp, i64, vp]),
+    "slim_lora_prune_workspace_bytes": (i64, [i64, i64, i64]),
+    "slim_lora_prune_optimize": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, f32, f32, vp, vp, i64, vp]),
     "slim_gemm_set_tile": (None, [i32]),
     "slim_gemm_set_trace": (None, [vp, i32]),
     "slim_eigh_workspace_bytes": (i64, [i32]),

@@ -199,6 +199,32 @@ class LoraContext:
         return (tuple(self.W.shape), self.rank, self.s is not None, self.outliers is None)
 
 
+# Adam iterations of the adapter re-fit after pruning (the reference's default, lora.py:11)
+PRUNE_LORA_ITERS = int(os.environ.get("SLIM_PRUNE_LORA_ITERS", "1000"))
+
+
+def prune_and_optimize_lora(L, R, num_iters=1000, lr_end_factor=1e-4):
+    """Prune L [K, r] 2:4 along K and re-fit L and R [r, N] to the product they had (lora.py:7-53).  L and R (bf16, on
+    the GPU) are updated in place; returns the bool mask of the pruned entries of L.  The mask marks the two SMALLEST
+    signed values of every four, as the reference's prune_nm call on L^T does.  r must be a multiple of 8 (callers
+    pad with zero columns, which stay zero)."""
+    if L.dtype != torch.bfloat16 or R.dtype != torch.bfloat16 or not L.is_cuda:
+        raise RuntimeError("prune_and_optimize_lora expects bf16 adapters on the GPU")
+    K, r = L.shape
+    N = R.shape[1]
+    if r % 8 or K % 4:
+        raise ValueError("prune_and_optimize_lora: the rank must be a multiple of 8 and K a multiple of 4")
+    Lc, Rc = L.contiguous(), R.contiguous()
+    _, T16, _ = ops.gemm_nt(Lc, ops.transpose(Rc), out_bf16=True)                 # torch.matmul(L, R) in bf16 (:25)
+    mask = ops.prune_nm_f32(Lc.t().float().contiguous(), 2, 4).t().contiguous()   # :27
+    Lc = Lc.masked_fill(mask, 0)
+    L32, R32 = Lc.float(), Rc.float()
+    ops.lora_prune_optimize(L32, R32, mask, T16.float(), num_iters, 1e6 / min(K, N) ** 2, lr_end_factor)
+    L.copy_(L32.to(torch.bfloat16))
+    R.copy_(R32.to(torch.bfloat16))
+    return mask
+
+
 def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None, quantizer=None, prune_lora=False,
                      separate_lora=True, lora_tile_size=None, quantize_first=False, scale_important_weights=False,
                      E_out=None, Et_out=None):
@@ -207,13 +233,14 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     strided buffer for the batched fit."""
     if scale_important_weights:
         raise NotImplementedError("scale_important_weights is not implemented")
-    if prune_lora:
-        raise NotImplementedError("prune_lora is not implemented")
+    if prune_lora and not separate_lora:
+        raise NotImplementedError("prune_lora needs separate adapters")          # lora.py:190-191
     W = module.weight.data
     if W.dtype != torch.bfloat16 or not W.is_cuda:
         raise RuntimeError("add_lora expects a bf16 weight on the GPU")
     c = LoraContext()
     c.module, c.quantizer, c.W_mask, c.separate = module, quantizer, W_mask, bool(separate_lora)
+    c.prune_lora, c.lora_left_mask = bool(prune_lora), None
     c.W = W.contiguous()
     N, K = c.W.shape
     c.bits = quantizer.num_bits if quantizer is not None else 4
@@ -266,8 +293,17 @@ def add_lora_fit(ctxs, E_group=None, Et_group=None):
     if E_group is None or len(ctxs) == 1:
         for c in ctxs:
             c.touch()
-            # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row)
-            c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if c.separate else None, c.outliers, c.spread)
+            # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row); pruned
+            # adapters are pruned and re-fitted before that division (lora.py:185-195)
+            scaled_in_fit = c.separate and not c.prune_lora
+            c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread)
+            if c.prune_lora:
+                U, Ut, L, info = c.fit
+                c.lora_left_mask = prune_and_optimize_lora(L, Ut, PRUNE_LORA_ITERS)
+                U = ops.transpose(Ut)
+                if c.s is not None:
+                    ops.scale_rows(L, c.s)
+                c.fit = (U, Ut, L, info)
         return
     assert len({c.group_key() for c in ctxs}) == 1 and ctxs[0].outliers is None and E_group.shape[0] == len(ctxs)
     assert all(c.separate for c in ctxs), "merged adapters are fitted one by one"
@@ -326,6 +362,8 @@ def add_lora_finish(c):
     module.lora_left = torch.nn.Parameter(lora_left).to(torch.bfloat16).contiguous()
     module.lora_right = torch.nn.Parameter(lora_right).to(torch.bfloat16).contiguous()
     module.weight.data = new_weight.to(torch.bfloat16).contiguous()
+    if c.lora_left_mask is not None:
+        module.lora_left_mask = c.lora_left_mask[:, :rank].contiguous()              # lora.py:210-211
     return sf_out
 
 

@@ -340,6 +340,23 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False,
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
 
+def lora_prune_optimize(L32, R32, L_mask, T32, num_iters, lr, lr_end_factor, want_losses=False):
+    """In place: num_iters Adam steps on fp32 L32 [K, r] (kept zero where L_mask) and R32 [r, N] towards T32 [K, N]."""
+    L32 = _chk(L32, torch.float32, "L32")
+    R32 = _chk(R32, torch.float32, "R32")
+    T32 = _chk(T32, torch.float32, "T32")
+    L_mask = _chk(L_mask, torch.bool, "L_mask")
+    K, r = L32.shape
+    N = R32.shape[1]
+    if tuple(R32.shape) != (r, N) or tuple(T32.shape) != (K, N) or tuple(L_mask.shape) != (K, r):
+        raise ValueError("shapes must be L [K, r], R [r, N], T [K, N], L_mask [K, r]")
+    losses = torch.empty(max(num_iters, 1), dtype=torch.float32, device=L32.device) if want_losses else None
+    ws = _ws(_lib.query("slim_lora_prune_workspace_bytes", K, r, N), L32.device)
+    _lib.call("slim_lora_prune_optimize", _p(L32), _p(R32), _p(L_mask), _p(T32), K, r, N, int(num_iters), float(lr),
+              float(lr_end_factor), _p(losses), _p(ws), ws.numel(), _stream())
+    return losses[:num_iters] if want_losses else None
+
+
 def scale_rows(L, s):
     """In place: L[k, :] = bf16(L[k, :] / bf16(s[k])) (the division of lora_left by sqrt(scaler_row))."""
     L = _chk(L, BF16, "L")

@@ -277,7 +277,7 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
     slot, buffers = {}, {}
     for key, members in groups.items():
         (N, K), _, _, batchable = key
-        if BATCH_FITS and separate_lora and batchable and len(members) > 1:
+        if BATCH_FITS and separate_lora and batchable and not prune_lora and len(members) > 1:
             buffers[key] = (torch.empty(len(members), N, K, dtype=torch.bfloat16, device=dev),
                             torch.empty(len(members), K, N, dtype=torch.bfloat16, device=dev))
             for b, idx in enumerate(members):
