@@ -118,19 +118,30 @@ def main():
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=7, help="HIP streams the linears of a block are spread over")
+    ap.add_argument("--rehearse-backend", default=None,
+                    help="rehearsal of the multi-rank path on fewer GPUs than ranks: process-group backend (gloo); ranks "
+                         "then share devices round-robin and the numbers mean nothing")
     ap.add_argument("--gemm-tile", type=int, default=-1, help="tuning aid: force one GEMM tile variant (slim_gemm_set_tile)")
     args = ap.parse_args()
 
+    if os.environ.get("SLIM_BENCH_WATCHDOG"):        # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SLIM_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rehearse_backend:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_backend:
+            dist.init_process_group(args.rehearse_backend)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from slim_amd import _lib
@@ -152,7 +163,7 @@ def main():
     W0 = {i: synth_weight(n, k, 100 + i, dev) for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK)}
     block_bytes = sum(2.0 * n * k for _, n, k, _ in LLAMA2_7B_BLOCK)
 
-    from slim_amd import ops
+    from slim_amd import ops, parallel
     from slim_amd.prune import compress_linears, block_stats
     from slim_amd.layerwrapper import shared_inputs
     from slim_amd.quantization.quantization import Quantizer
@@ -184,7 +195,7 @@ def main():
                     lin.lora_left = torch.nn.Parameter(torch.empty(k, r, dtype=torch.bfloat16, device=dev))
                     lin.lora_right = torch.nn.Parameter(torch.empty(r, n, dtype=torch.bfloat16, device=dev))
                 for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data):
-                    dist.broadcast(t, src=owner[i])
+                    parallel.broadcast(t, owner[i])          # RCCL broadcast (host-staged only under a gloo rehearsal)
 
     def barrier():
         if world > 1:
@@ -223,7 +234,7 @@ def main():
         prof_single = _lib.profile_summary()
         _lib.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.rehearse_backend else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
