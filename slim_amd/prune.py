@@ -71,6 +71,9 @@ def block_stats(wrapped_list):
 # SLIM_STREAM_TRACE=1: run_on_streams records, per job, when its host thread started / finished enqueueing and when its
 # stream started / finished executing it (ms after the call), into LAST_STREAM_TRACE; costs a device sync per call
 STREAM_TRACE = os.environ.get("SLIM_STREAM_TRACE", "0") == "1"
+# SLIM_STREAM_THREADS=0: the calling thread feeds the side streams one after the other (slower: one thread enqueues
+# everything; for profilers that do not tolerate dispatches from several threads)
+STREAM_THREADS = os.environ.get("SLIM_STREAM_THREADS", "1") != "0"
 LAST_STREAM_TRACE = []
 
 
@@ -117,11 +120,15 @@ def run_on_streams(jobs, dev, n_streams=None):
         except BaseException as e:              # re-raised on the calling thread
             errors.append(e)
 
-    threads = [threading.Thread(target=feed, args=(si,), name=f"slim-stream-{si}") for si in range(len(streams))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    if STREAM_THREADS:
+        threads = [threading.Thread(target=feed, args=(si,), name=f"slim-stream-{si}") for si in range(len(streams))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    else:
+        for si in range(len(streams)):
+            feed(si)
     for st in streams:
         main.wait_stream(st)
     if errors:
