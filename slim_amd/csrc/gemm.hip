@@ -89,6 +89,8 @@ __device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, int& row0, int& co
         if (g.C16) g.C16 += bz * g.sC16;
         if (g.Ct16) g.Ct16 += bz * g.sCt;
         if (g.slab) g.slab += bz * g.sSlab;
+        if (g.poly_G) g.poly_G += bz * g.poly_sG;
+        if (g.poly_scal) g.poly_scal += bz * g.poly_sScal;
     }
 
 }
@@ -199,6 +201,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
                             for (int u = 0; u < 4; ++u)
                                 if (u < nc) p[u] = lr16[u];
                     }
+                }
+            } else if (g.poly_G) {
+                // the polynomial of a Newton-Schulz step, evaluated where the tile of G G is still on chip; every value of
+                // G is fetched before the first store (see above), the arithmetic is the stand-alone polynomial kernel's
+                const float sc = g.poly_scal ? *g.poly_scal : 1.f;
+                const float c2 = sc * sc;
+                const bool vg = nc >= 4 && (g.N & 3) == 0 && ((uintptr_t)g.poly_G & 15) == 0;
+                const bool v16 = nc >= 4 && (g.ldc16 & 3) == 0 && ((uintptr_t)g.C16 & 7) == 0;
+                float gv[ITERS][4];
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int row = row0 + rt + it * RSTEP;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) gv[it][u] = 0.f;
+                    if (row >= g.M) continue;
+                    const float* p = g.poly_G + (int64_t)row * g.N + col;
+                    if (vg) {
+                        const f32x4 t4 = *(const f32x4*)p;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gv[it][u] = t4[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nc) gv[it][u] = p[u];
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int r = rt + it * RSTEP, row = row0 + r;
+                    if (row >= g.M) continue;
+                    bf16_t o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float v = g.poly_b * c2 * gv[it][u] + g.poly_q * c2 * c2 * T[r * TS + c + u];
+                        if (row == col + u) v += g.poly_a;
+                        o[u] = f32_to_bf16(sc * v);
+                    }
+                    bf16_t* p = g.C16 + (int64_t)row * g.ldc16 + col;
+                    if (v16) *(u16x4*)p = u16x4{o[0], o[1], o[2], o[3]};
+                    else
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nc) p[u] = o[u];
                 }
             } else {
                 const bool v32 = nc >= 4 && (g.ldc32 & 3) == 0 && ((uintptr_t)g.C32 & 15) == 0;
@@ -574,6 +619,8 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     SLIM_REQUIRE(g.C32 || g.C16 || g.Ct16 || g.Wn, "slim_gemm_nt_bf16: no output requested");
     SLIM_REQUIRE(!g.Ct16 || (((uintptr_t)g.Ct16 % 8) == 0 && g.beta == 0.f),
                  "slim_gemm_nt_bf16: Ct must be 8-byte aligned and cannot be combined with beta");
+    SLIM_REQUIRE(!g.poly_G || (g.C16 && !g.C32 && !g.Ct16 && !g.Wn && g.splits <= 1 && g.beta == 0.f && g.M == g.N),
+                 "slim_gemm_nt_bf16: the polynomial epilogue writes C_bf16 only, of a square product");
     const int batch = g.batch > 1 ? g.batch : 1;
     SLIM_REQUIRE(batch <= 65535 && (batch == 1 || (!g.Wn && g.beta == 0.f)), "slim_gemm_nt_bf16: bad batch arguments");
     const int tile = gemm_pick_tile(g, batch);

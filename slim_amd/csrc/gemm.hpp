@@ -29,6 +29,12 @@ struct GemmArgs {
     // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
     int batch = 1;
     int64_t sA = 0, sB = 0, sC32 = 0, sC16 = 0, sCt = 0, sSlab = 0;
+    // optional fused epilogue of a Newton-Schulz step: with acc = G G, C16 = bf16(c * (a I + b c^2 G + q c^4 acc)),
+    // c = *poly_scal (1 when NULL); needs M == N, no other output form
+    const float* poly_G = nullptr;
+    const float* poly_scal = nullptr;
+    float poly_a = 0.f, poly_b = 0.f, poly_q = 0.f;
+    int64_t poly_sG = 0, poly_sScal = 0;      // batch strides of poly_G / poly_scal
     // tuning aid (slim_gemm_set_trace): when set, workgroup w < trace_cap stores 100 MHz timestamps at
     // trace[8 w ..]: kernel entry, first tile staged, K-loop done, epilogue done
     int64_t* trace = nullptr;

@@ -400,10 +400,30 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
             fro_rsqrt_kernel<<<w.batch, 64, 0, st>>>(w.fro_part, w.scal);
             SLIM_LAUNCH_CHECK();
         }
-        if (quintic) CHK(nt(w.batch, w.G16, l, sG, w.G16, l, sG, l, l, l, w.G2, nullptr, l, nullptr, 0, stream));
-        ns_poly_kernel<<<pgrid, 256, 0, st>>>(w.G, w.G2, sidx == 0 ? w.scal : nullptr, quintic ? 3.4445f : 1.5f,
-                                              quintic ? -4.7750f : -0.5f, quintic ? 2.0315f : 0.f, l, w.T16);
-        SLIM_LAUNCH_CHECK();
+        if (quintic) {
+            // G G with the polynomial evaluated in the product's epilogue: P = c (a I + b c^2 G + q c^4 G G) as bf16
+            GemmArgs pg;
+            pg.A = w.G16;
+            pg.lda = l;
+            pg.B = w.G16;
+            pg.ldb = l;
+            pg.M = pg.N = pg.Kd = l;
+            pg.C16 = w.T16;
+            pg.ldc16 = l;
+            pg.batch = w.batch;
+            pg.sA = pg.sB = pg.sC16 = sG;
+            pg.poly_G = w.G;
+            pg.poly_sG = sG;
+            pg.poly_scal = sidx == 0 ? w.scal : nullptr;
+            pg.poly_sScal = SCAL_STRIDE;
+            pg.poly_a = 3.4445f;
+            pg.poly_b = -4.7750f;
+            pg.poly_q = 2.0315f;
+            CHK(slim_gemm_launch(pg, stream));
+        } else {
+            ns_poly_kernel<<<pgrid, 256, 0, st>>>(w.G, w.G2, sidx == 0 ? w.scal : nullptr, 1.5f, -0.5f, 0.f, l, w.T16);
+            SLIM_LAUNCH_CHECK();
+        }
         // P is symmetric, so it serves as its own transpose in the NT product X P
         CHK(nt(w.batch, x.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, bufs[nxt].X, l, bufs[nxt].Xt, rows, stream));
         cur = nxt;
