@@ -452,3 +452,25 @@ def test_shared_input_statistics_are_bit_identical(ops):
     assert len(calls) == 2                      # once per distinct input tensor, not once per linear
     for w in shared:
         assert w.nsamples == 6 and torch.equal(w.scaler_row, plain.scaler_row)
+
+
+def test_lowrank_fit_library_eigh_agrees(ops):
+    """The fit with the Rayleigh-Ritz eigenproblem on rocSOLVER syevd (the path taken for subspaces larger than the
+    in-library solver supports) against the default in-library solver: same reconstruction error, same singular values."""
+    from slim_amd.lora import FIT_ITERS
+    N, K, r = 1024, 768, 96
+    W = synth_weight(N, K, 91)
+    sr = O.shift_zeros(synth_scaler(K, 92))
+    mask = O.prune_nm(O.saliency(W, sr), 2, 4)
+    E = O.add_lora(W, mask, sr, 0.1, tile=None)["error_mat"]
+    Eb = g2d(E.to(torch.bfloat16))
+    Et = Eb.t().contiguous()
+    Ef = E.to(torch.bfloat16).float()
+    outs = {}
+    for lib in (False, True):
+        f = ops.lowrank_fit(Eb, Et, r, 64, FIT_ITERS, seed=0, library_eigh=lib)
+        assert int(f["info"].abs().sum()) == 0
+        outs[lib] = (torch.norm(Ef - f["U"].cpu().float() @ f["L"].cpu().float().t()).item(), f["S"].cpu())
+    print("reconstruction error: in-library", outs[False][0], "syevd", outs[True][0])
+    assert abs(outs[False][0] / outs[True][0] - 1) <= 2e-4
+    torch.testing.assert_close(outs[False][1][: r // 2], outs[True][1][: r // 2], rtol=1e-4, atol=0)
