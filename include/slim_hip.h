@@ -26,6 +26,7 @@ extern "C" {
 #define SLIM_FIT_INFO_WORDS 64
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_ONE_SIDED 2   /* re-orthonormalise only the row-side iterate (once per full iteration) */
+#define SLIM_FIT_EXACT_FINAL 8  /* last basis finished by Cholesky-QR (rocSOLVER) instead of the fp32 inverse-square-root polish */
 #define SLIM_FIT_LIBRARY_EIGH 4 /* Rayleigh-Ritz eigenproblem through rocSOLVER syevd instead of slim_eigh_f32's method */
 
 int slim_abi_version(void);

@@ -380,6 +380,60 @@ static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, Fi
     return nt(w.batch, src.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, dst.X, l, dst.Xt, rows, stream);
 }
 
+// dst <- X G^(-1/2), G = X^T X: the polish of a basis that Newton-Schulz has already brought close to orthonormal
+// (eigenvalues of G within [0.46, 1.28]).  G^(-1/2) comes from the coupled Newton-Schulz iteration
+//     T = (3 I - Z Y) / 2,  Y <- Y T,  Z <- T Z,   Y0 = G, Z0 = I   (Y -> G^(1/2), Z -> G^(-1/2), error squared per step)
+// on the l x l matrices in fp32 (library GEMMs: three per step, a dozen microseconds each), which replaces the
+// Cholesky factorisation and triangular inversion of cholesky_qr (forty-odd solver launches, 1.6 ms at l = 640,
+// most of it in single-workgroup diagonal-block kernels).  A direction the iterate has lost entirely (eigenvalue
+// of G near zero) is not restored by this -- its column stays near zero and drops to the bottom of the
+// Rayleigh-Ritz spectrum; cholesky_qr remains the choice where the basis must span the whole space.
+__global__ void scaled_identity_kernel(float* __restrict__ a, int l, float value) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < l) a[(int64_t)blockIdx.z * l * l + (int64_t)i * l + j] = i == j ? value : 0.f;
+}
+
+#define POLISH_STEPS 5
+static int invsqrt_qr(const Pair& src, const Pair& dst, int64_t rows, int l, FitWs& w, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    rb_handle h = nullptr;
+    CHK(solver_handle(st, &h));
+    SLIM_REQUIRE(g_solver.sgemm, "slim_lowrank_fit: rocblas_sgemm not available");
+    CHK(gram(src.Xt, rows, l, w, nullptr, stream));
+    const int64_t sG = (int64_t)l * l;
+    const dim3 grid((unsigned)((l + 255) / 256), (unsigned)l, (unsigned)w.batch);
+    const float one = 1.f, zero = 0.f, mhalf = -0.5f, threehalves = 1.5f;
+    int tok = g_slim_prof_on ? slim_prof_begin("polish_invsqrt", st, 0.0, 6.0 * POLISH_STEPS * l * (double)l * l * w.batch) : -1;
+    // the split-K slab is free between Gram products: Z, its successor and T live there
+    float* Y = w.G;
+    float* Y2 = w.G2;
+    float* Z = w.slab;
+    float* Z2 = w.slab + sG * w.batch;
+    float* T = w.slab + 2 * sG * w.batch;
+    scaled_identity_kernel<<<grid, 256, 0, st>>>(Z, l, 1.f);
+    SLIM_LAUNCH_CHECK();
+    for (int it = 0; it < POLISH_STEPS; ++it) {
+        scaled_identity_kernel<<<grid, 256, 0, st>>>(T, l, 1.f);
+        SLIM_LAUNCH_CHECK();
+        for (int b = 0; b < w.batch; ++b) {
+            float *y = Y + b * sG, *y2 = Y2 + b * sG, *z = Z + b * sG, *z2 = Z2 + b * sG, *t = T + b * sG;
+            // every matrix here is a polynomial in G: symmetric, so row- and column-major views coincide
+            if (g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, l, l, l, &mhalf, z, l, y, l, &threehalves, t, l) != 0 ||
+                g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, l, l, l, &one, y, l, t, l, &zero, y2, l) != 0 ||
+                g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, l, l, l, &one, t, l, z, l, &zero, z2, l) != 0) {
+                slim_set_error("rocblas_sgemm failed");
+                return SLIM_ERR_SOLVER;
+            }
+        }
+        float* tmp = Y; Y = Y2; Y2 = tmp;
+        tmp = Z; Z = Z2; Z2 = tmp;
+    }
+    if (tok >= 0) slim_prof_end(tok, st);
+    ns_poly_kernel<<<grid, 256, 0, st>>>(Z, nullptr, nullptr, 0.f, 1.f, 0.f, l, w.T16);      // bf16(Z)
+    SLIM_LAUNCH_CHECK();
+    return nt(w.batch, src.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, dst.X, l, dst.Xt, rows, stream);
+}
+
 // Newton-Schulz orthonormalisation on MFMA: X <- X p(X^T X) keeps the column space and drives every
 // singular value towards 1.  `nq` quintic steps (3.4445, -4.7750, 2.0315: fast, settles in [0.68, 1.13]),
 // then `nc` cubic steps (1.5, -0.5: converges to 1 quadratically).  Each step is the l x l Gram matrix
@@ -442,13 +496,13 @@ static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int f
         return SLIM_OK;
     }
     if (!final_pass) return ns_orth(bufs, cur, rows, l, nq, 0, w, stream, out_idx);
-    // last basis before the Rayleigh-Ritz step: it must be orthonormal in every direction, including ones the
-    // polynomial iteration has not lifted yet (a numerically rank-deficient iterate), so finish with an exact
-    // Cholesky-QR on the Newton-Schulz-conditioned matrix
+    // last basis before the Rayleigh-Ritz step: the polynomial iteration leaves the singular values within [0.68, 1.13];
+    // an fp32 inverse-square-root polish (or, on request, an exact Cholesky-QR) brings them to 1
     int mid = cur;
     CHK(ns_orth(bufs, cur, rows, l, nq, 0, w, stream, &mid));
     const int nxt = (mid + 1) % 3;
-    CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
+    if (flags & SLIM_FIT_EXACT_FINAL) CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
+    else CHK(invsqrt_qr(bufs[mid], bufs[nxt], rows, l, w, stream));
     *out_idx = nxt;
     return SLIM_OK;
 }

@@ -308,7 +308,7 @@ def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
 
 
 def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0, one_sided=False,
-                library_eigh=False):
+                library_eigh=False, exact_final=False):
     """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info).
     E [B, N, K] (with Et [B, K, N], s [B, K]) runs B fits of identical shape in lockstep and returns
     tensors with a leading batch dimension."""
@@ -335,7 +335,7 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False,
     S = torch.empty(*lead, r, dtype=torch.float32, device=dev)
     info = torch.empty(*lead, 64, dtype=torch.int32, device=dev)
     ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", B, N, K, l), dev)
-    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)) | (2 if one_sided else 0) | (4 if library_eigh else 0),
+    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)) | (2 if one_sided else 0) | (4 if library_eigh else 0) | (8 if exact_final else 0),
               int(ns_steps), _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
