@@ -104,3 +104,37 @@ def test_argument_errors(ops):
         ops.lowrank_fit(synth_weight(64, 64, 3).to(DEV), synth_weight(64, 64, 3).to(DEV).t().contiguous(), 60, 8, 2)  # r % 8
     with pytest.raises(ValueError):
         ops.mask_unstructured(synth_weight(16, 16, 2).to(DEV), torch.ones(16, device=DEV), 17)
+
+
+def test_stream_feeding_modes_agree(ops):
+    """compress_linears fed by one host thread per stream, by the calling thread alone, and with the per-job timeline on:
+    identical tensors (the stream a job runs on never changes its result)."""
+    import slim_amd.prune as P
+    from slim_amd.layerwrapper import WrappedGPT
+    from slim_amd.quantization.quantization import Quantizer
+
+    def run(threads, trace):
+        old = P.STREAM_THREADS, P.STREAM_TRACE
+        P.STREAM_THREADS, P.STREAM_TRACE = threads, trace
+        try:
+            items = []
+            for i in range(3):
+                lin = torch.nn.Linear(256, 128, bias=False, device=DEV, dtype=torch.bfloat16)
+                lin.weight.data = synth_weight(128, 256, 40 + i).to(DEV)
+                wr = WrappedGPT(lin)
+                wr.add_batch(synth_weight(64, 256, 50 + i, sigma=1.0).to(DEV).reshape(1, 64, 256), None)
+                wr.scaler_row = ops.shift_zeros(wr.scaler_row)
+                items.append((f"l{i}", lin, wr))
+            P.compress_linears(items, torch.device(DEV), 2, 4, quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
+                               lora_rank=0.1, slim_lora=True, n_streams=3)
+            torch.cuda.synchronize()
+            return [(lin.weight.data.clone(), lin.lora_left.data.clone(), lin.lora_right.data.clone()) for _, lin, _ in items]
+        finally:
+            P.STREAM_THREADS, P.STREAM_TRACE = old
+
+    base = run(True, False)
+    for threads, trace in ((False, False), (True, True)):
+        other = run(threads, trace)
+        for a, b in zip(base, other):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert len(P.LAST_STREAM_TRACE) == 3 and all(r["gpu_end_ms"] >= r["gpu_start_ms"] for r in P.LAST_STREAM_TRACE)
