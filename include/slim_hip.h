@@ -27,6 +27,7 @@ extern "C" {
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_ONE_SIDED 2   /* re-orthonormalise only the row-side iterate (once per full iteration) */
 #define SLIM_FIT_EXACT_FINAL 8  /* last basis finished by Cholesky-QR (rocSOLVER) instead of the fp32 inverse-square-root polish */
+#define SLIM_FIT_NO_SKETCH_SPLIT 16 /* never cut the sketch products along the reduction (by default the ones that under-fill the chip are) */
 #define SLIM_FIT_LIBRARY_EIGH 4 /* Rayleigh-Ritz eigenproblem through rocSOLVER syevd instead of slim_eigh_f32's method */
 
 int slim_abi_version(void);
@@ -152,6 +153,10 @@ int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, i
 int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
                              float alpha, float* C_f32, int64_t ldc32, void* C_bf16, int64_t ldc16, int splits,
                              float* slab, void* stream);
+/* the same with C_bf16 (optional) and its transpose Ct_bf16 [N, M] as outputs; slab holds splits * M * N floats */
+int slim_gemm_nt_bf16_splitk_t(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
+                               float alpha, void* C_bf16, int64_t ldc16, void* Ct_bf16, int64_t ldct, int splits,
+                               float* slab, void* stream);
 
 /* Adapter pruning, the optimisation loop of prune_and_optimize_lora (slim/lora.py:28-50): num_iters Adam steps
  * (torch defaults; lr decaying linearly to lr * lr_end_factor) on fp32 L [K, r] (zero where L_mask is set and kept so)

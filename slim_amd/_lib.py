@@ -53,6 +53,7 @@ PROTOTYPES = {
     "slim_orthonormalize_bf16": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_fit_workspace_bytes": (i64, [i64, i64, i64]),
     "slim_gemm_nt_bf16_splitk": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, vp, i64, vp, i64, i32, vp, vp]),
+    "slim_gemm_nt_bf16_splitk_t": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, vp, i64, vp, i64, i32, vp, vp]),
     "slim_lowrank_fit": (i32, [vp, vp, i64, i64, i32, i32, i32, u32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_fit_batched_workspace_bytes": (i64, [i32, i64, i64, i64]),
     "slim_lowrank_fit_batched": (i32, [vp, vp, i32, i64, i64, i32, i32, i32, u32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),

@@ -568,6 +568,77 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     if (C16) C16[row * ldc16 + col] = f32_to_bf16(v);
 }
 
+// The same reduction for products that also want the transposed bf16 output (the sketch products of the fit): a
+// 64 x 64 tile per workgroup, summed slice by slice into LDS, written as rows of C and as rows of C^T.
+__global__ __launch_bounds__(256) void splitk_reduce_t_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                                              float alpha, bf16_t* __restrict__ C16, int64_t ldc16,
+                                                              bf16_t* __restrict__ Ct16, int64_t ldct, int64_t sSlab,
+                                                              int64_t sC16, int64_t sCt) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const int64_t bz = blockIdx.z;
+    slab += bz * sSlab;
+    if (C16) C16 += bz * sC16;
+    if (Ct16) Ct16 += bz * sCt;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const int64_t n = (int64_t)M * N;
+    const int tx = (t & 15) * 4, ty = t >> 4;
+    const bool vec = (N & 3) == 0 && ((uintptr_t)slab & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 16 * i, row = row0 + r, col = col0 + tx;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < M && col < N) {
+            const float* p = slab + (int64_t)row * N + col;
+            if (vec && col + 3 < N) {
+                for (int z = 0; z < splits; ++z) {
+                    const f32x4 q = *(const f32x4*)(p + (int64_t)z * n);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] += q[u];
+                }
+            } else {
+                for (int z = 0; z < splits; ++z)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (col + u < N) v[u] += p[(int64_t)z * n + u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] *= alpha;
+            tile[r][tx + u] = v[u];
+        }
+        if (C16 && row < M && col < N) {
+            bf16_t* o = C16 + (int64_t)row * ldc16 + col;
+            if (col + 3 < N && (ldc16 & 3) == 0 && ((uintptr_t)C16 & 7) == 0)
+                *(u16x4*)o = u16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+            else
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (col + u < N) o[u] = f32_to_bf16(v[u]);
+        }
+    }
+    __syncthreads();
+    if (Ct16) {
+        const int c = t >> 2, r0 = (t & 3) * 16, col = col0 + c;     // one C^T row per four lanes, 16 values each
+        if (col < N) {
+            bf16_t* o = Ct16 + (int64_t)col * ldct + row0 + r0;
+            const bool v8 = (ldct & 7) == 0 && ((uintptr_t)Ct16 & 15) == 0 && row0 + r0 + 15 < M;
+            bf16_t h[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) h[u] = f32_to_bf16(tile[r0 + u][c]);
+            if (v8) {
+                *(u16x8*)o = u16x8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+                *(u16x8*)(o + 8) = u16x8{h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]};
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (row0 + r0 + u < M) o[u] = h[u];
+            }
+        }
+    }
+}
+
 typedef void (*gemm_kernel_t)(GemmArgs);
 template <int FAMILY>
 static gemm_kernel_t gemm_kernel_of(int tile) {
@@ -656,10 +727,19 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                                                                       (g.Ct16 ? 2.0 : 0.0) + (g.Wn ? 5.0 : 0.0)),
               2.0 * g.M * g.N * g.Kd * batch);
     if (g.splits > 1) {
-        SLIM_REQUIRE(g.slab && !g.Ct16 && !g.Wn, "slim_gemm_nt_bf16: split-K supports C_f32 / C_bf16 outputs only");
+        SLIM_REQUIRE(g.slab && !g.Wn && !(g.Ct16 && (g.C32 || g.beta != 0.f)),
+                     "slim_gemm_nt_bf16: split-K supports C_f32 / C_bf16 outputs, or C_bf16 / C^T_bf16");
         dim3 grid((unsigned)tiles, (unsigned)g.splits, (unsigned)batch);
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, g);
         SLIM_LAUNCH_CHECK();
+        if (g.Ct16) {
+            dim3 tgrid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)batch);
+            SLIM_REQUIRE(tgrid.y <= 65535, "slim_gemm_nt_bf16: too many rows for the transposing reduction");
+            splitk_reduce_t_kernel<<<tgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, g.M, g.N, g.alpha, g.C16, g.ldc16,
+                                                                           g.Ct16, g.ldct, g.sSlab, g.sC16, g.sCt);
+            SLIM_LAUNCH_CHECK();
+            return SLIM_OK;
+        }
         const int64_t n = (int64_t)g.M * g.N;
         dim3 rgrid((unsigned)ceil_div64(n, 256), (unsigned)batch);
         splitk_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32,
@@ -696,6 +776,30 @@ extern "C" int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* 
     g.ksteps_per_split = (nk + splits - 1) / splits;
     g.splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     g.slab = slab;
+    return slim_gemm_launch(g, stream);
+}
+
+// Split-K with the bf16 result and its transpose as outputs (the form the sketch products of the fit use).
+extern "C" int slim_gemm_nt_bf16_splitk_t(const void* A, int64_t lda, const void* Bt, int64_t ldb, int M, int N, int Kd,
+                                          float alpha, void* C_bf16, int64_t ldc16, void* Ct_bf16, int64_t ldct, int splits,
+                                          float* slab, void* stream) {
+    SLIM_REQUIRE(splits >= 1 && (splits == 1 || slab) && Ct_bf16, "slim_gemm_nt_bf16_splitk_t: bad arguments");
+    GemmArgs g{};
+    g.A = (const bf16_t*)A;
+    g.lda = lda;
+    g.B = (const bf16_t*)Bt;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.Kd = Kd;
+    g.alpha = alpha;
+    g.C16 = (bf16_t*)C_bf16;
+    g.ldc16 = ldc16;
+    g.Ct16 = (bf16_t*)Ct_bf16;
+    g.ldct = ldct;
+    g.slab = slab;
+    gemm_plan_splits(g, splits);
+    if (g.splits <= 1) g.slab = nullptr;
     return slim_gemm_launch(g, stream);
 }
 

@@ -208,6 +208,7 @@ __global__ void ns_poly_kernel(const float* __restrict__ G, const float* __restr
 
 // ---- workspace ----------------------------------------------------------------------------------
 #define GRAM_MAX_SPLITS 16
+#define SKETCH_MAX_SPLITS 3
 static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 
 struct Pair {
@@ -226,6 +227,7 @@ struct FitWs {
     float* scal;    // [batch][SCAL_STRIDE]
     double* fro_part;  // [batch][FRO_BLOCKS] partial sums of squares
     float* slab;    // [batch][GRAM_MAX_SPLITS, l, l] split-K partials of the Gram products
+    float* sketch_slab;  // [batch][SKETCH_MAX_SPLITS, l, max(N, K)] split-K partials of the sketch products
     int* info;      // [batch][SLIM_FIT_INFO_WORDS]
     int* info_tmp;  // [batch] status words of one batched solver call
     int64_t total;
@@ -256,6 +258,7 @@ static FitWs fit_ws(char* base, int batch, int64_t N, int64_t K, int64_t l) {
     w.scal = (float*)take(SCAL_STRIDE * 4);
     w.fro_part = (double*)take(FRO_BLOCKS * 8);
     w.slab = (float*)take((int64_t)GRAM_MAX_SPLITS * l * l * 4);
+    w.sketch_slab = (float*)take((int64_t)SKETCH_MAX_SPLITS * l * (N > K ? N : K) * 4);
     w.info = (int*)take(SLIM_FIT_INFO_WORDS * 4);
     w.info_tmp = (int*)take(4);
     w.total = o;
@@ -279,7 +282,8 @@ extern "C" int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_
 // Strided-batched NT product: C[b] = A[b] (M x Kd, row stride lda) * Bt[b]^T (N x Kd, row stride ldb); a
 // stride of 0 shares the operand between the problems.  Outputs as in slim_gemm_nt_bf16.
 static int nt(int batch, const bf16_t* A, int64_t lda, int64_t sA, const bf16_t* Bt, int64_t ldb, int64_t sB, int M, int N,
-              int Kd, float* C32, bf16_t* C16, int64_t ldc, bf16_t* Ct16, int64_t ldct, void* stream) {
+              int Kd, float* C32, bf16_t* C16, int64_t ldc, bf16_t* Ct16, int64_t ldct, void* stream, float* split_slab = nullptr,
+              int64_t split_slab_stride = 0) {
     GemmArgs g;
     g.A = A;
     g.lda = lda;
@@ -298,6 +302,20 @@ static int nt(int batch, const bf16_t* A, int64_t lda, int64_t sA, const bf16_t*
     g.sA = sA;
     g.sB = sB;
     g.sC32 = g.sC16 = g.sCt = (int64_t)M * N;
+    if (split_slab && !C32) {
+        // a product whose tile grid leaves most of the chip idle (the l x 4096 sketches: 160 tiles on 256 CUs, one
+        // latency-bound workgroup each) is cut along the reduction; the split depends on the shape only
+        const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+        const int nk = (Kd + 63) / 64;
+        int splits = tiles >= 256 ? 1 : (int)((512 + tiles - 1) / tiles);
+        if (splits > SKETCH_MAX_SPLITS) splits = SKETCH_MAX_SPLITS;
+        if (splits > nk / 8) splits = nk / 8;              // at least eight K-steps per slice
+        if (splits > 1) {
+            g.slab = split_slab;
+            g.sSlab = split_slab_stride;
+            gemm_plan_splits(g, splits);
+        }
+    }
     return slim_gemm_launch(g, stream);
 }
 
@@ -564,6 +582,8 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     const bf16_t* Eb = (const bf16_t*)E;
     const bf16_t* Etb = (const bf16_t*)Et;
     const int64_t sE = N * K, sYn = N * l, sZk = K * l, sG = (int64_t)l * l;
+    const int64_t sSk = (int64_t)SKETCH_MAX_SPLITS * l * (N > K ? N : K);
+    float* sk_slab = (flags & SLIM_FIT_NO_SKETCH_SPLIT) ? nullptr : w.sketch_slab;
     int ninfo = 0, a = 0, b = 0;
     const int nq = ns_steps > 0 ? (ns_steps > 16 ? 16 : ns_steps) : 4;
     // when the subspace is the whole space the basis must be orthonormal to working precision in every
@@ -572,11 +592,11 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
 
     // Y^T = P0^T E^T  (A = P0^T [l, K], Bt = E [N, K]) -> Y^T [l, N] and Y [N, l]
     auto sketch_rows = [&](const bf16_t* Pt) {
-        return nt(batch, Pt, K, sZk, Eb, K, sE, l, (int)N, (int)K, nullptr, w.A[0].Xt, N, w.A[0].X, l, stream);
+        return nt(batch, Pt, K, sZk, Eb, K, sE, l, (int)N, (int)K, nullptr, w.A[0].Xt, N, w.A[0].X, l, stream, sk_slab, sSk);
     };
     // Z^T = Q^T E  (A = Q^T [l, N], Bt = E^T [K, N]) -> Z^T [l, K] and Z [K, l]
     auto sketch_cols = [&](const bf16_t* Qt) {
-        return nt(batch, Qt, N, sYn, Etb, N, sE, l, (int)K, (int)N, nullptr, w.B[0].Xt, K, w.B[0].X, l, stream);
+        return nt(batch, Qt, N, sYn, Etb, N, sE, l, (int)K, (int)N, nullptr, w.B[0].Xt, K, w.B[0].X, l, stream, sk_slab, sSk);
     };
 
     // P0^T [l, K]: Gaussian test matrix;  Y = E P0;  Q = orth(Y)

@@ -32,6 +32,8 @@ FIT_ONE_SIDED = os.environ.get("SLIM_FIT_ONE_SIDED", "0") == "1"
 FIT_LIBRARY_EIGH = os.environ.get("SLIM_FIT_LIBRARY_EIGH", "0") == "1"
 # last basis before the Rayleigh-Ritz step finished by Cholesky-QR (rocSOLVER potrf + trtri) instead of the fp32 polish
 FIT_EXACT_FINAL = os.environ.get("SLIM_FIT_EXACT_FINAL", "0") == "1"
+# split-K for the sketch products whose tile grid under-fills the chip
+FIT_SKETCH_SPLIT = os.environ.get("SLIM_FIT_SKETCH_SPLIT", "1") == "1"
 
 
 def fit_ns_steps(spread):
@@ -84,7 +86,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     if t == 0 or rank - t < 8:
         over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
         fit = ops.lowrank_fit(E, Et, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
-                              cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL)
+                              cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
         U, Ut, L = fit["U"], fit["Ut"], fit["L"]
         if U.shape[1] != r8:           # rank above the largest multiple of 8 within min(N, K)
             raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
@@ -113,7 +115,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     rf = _round_up8(rank - t)
     over = max(FIT_MIN_OVERSAMPLE, rf // FIT_OVERSAMPLE_DIV)
     fit = ops.lowrank_fit(E2, ops.transpose(E2), rf, over, FIT_ITERS, seed=FIT_SEED, s=s,
-                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL)
+                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
     LO = ops.scale_rows(Ct, s) if s is not None else Ct
     U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
     L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
@@ -317,7 +319,7 @@ def add_lora_fit(ctxs, E_group=None, Et_group=None):
     over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
     s = torch.stack([c.s for c in ctxs]).contiguous() if ctxs[0].s is not None else None
     fit = ops.lowrank_fit(E_group, Et_group, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
-                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=max(fit_ns_steps(c.spread) for c in ctxs), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL)
+                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=max(fit_ns_steps(c.spread) for c in ctxs), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
     U, Ut, L = fit["U"], fit["Ut"], fit["L"]
     if U.shape[-1] != r8:
         raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")

@@ -265,6 +265,20 @@ def gemm_nt_splitk(A, Bt, splits, alpha=1.0):
     return C32, C16
 
 
+def gemm_nt_splitk_t(A, Bt, splits, alpha=1.0):
+    """(C bf16, C^T bf16) = alpha * A @ Bt.T with the reduction split into `splits` deterministic slices."""
+    A = _chk(A, BF16, "A")
+    Bt = _chk(Bt, BF16, "Bt")
+    M, Kd = A.shape
+    N = Bt.shape[0]
+    C16 = torch.empty(M, N, dtype=BF16, device=A.device)
+    Ct = torch.empty(N, M, dtype=BF16, device=A.device)
+    slab = torch.empty(max(splits, 1) * M * N, dtype=torch.float32, device=A.device)
+    _lib.call("slim_gemm_nt_bf16_splitk_t", _p(A), Kd, _p(Bt), Kd, M, N, Kd, float(alpha), _p(C16), N, _p(Ct), M, splits,
+              _p(slab), _stream())
+    return C16, Ct
+
+
 def tridiagonalize(G):
     """(d [n], e [n-1], Q [n, n]) with Q.T @ G @ Q = tridiag(d, e) for a symmetric fp32 matrix G."""
     G = _chk(G, torch.float32, "G").clone()
@@ -308,7 +322,7 @@ def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
 
 
 def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0, one_sided=False,
-                library_eigh=False, exact_final=False):
+                library_eigh=False, exact_final=False, sketch_split=True):
     """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info).
     E [B, N, K] (with Et [B, K, N], s [B, K]) runs B fits of identical shape in lockstep and returns
     tensors with a leading batch dimension."""
@@ -335,7 +349,7 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False,
     S = torch.empty(*lead, r, dtype=torch.float32, device=dev)
     info = torch.empty(*lead, 64, dtype=torch.int32, device=dev)
     ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", B, N, K, l), dev)
-    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)) | (2 if one_sided else 0) | (4 if library_eigh else 0) | (8 if exact_final else 0),
+    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(bool(cholesky_qr)) | (2 if one_sided else 0) | (4 if library_eigh else 0) | (8 if exact_final else 0) | (0 if sketch_split else 16),
               int(ns_steps), _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 

@@ -41,3 +41,6 @@ def test_gemm_variant_matches_reference(variant):
             S32, S16 = ops.gemm_nt_splitk(A, Bt, splits=3)
             assert (S32.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (variant, M, N, Kd, "split")
             assert torch.equal(S16, S32.to(torch.bfloat16))
+            T16, Tt = ops.gemm_nt_splitk_t(A, Bt, splits=3, alpha=0.5)
+            assert torch.equal(Tt, T16.t()), (variant, M, N, Kd, "split, transposed")
+            assert (T16.double() - 0.5 * ref).abs().max().item() <= (tol + 2 ** -8) * max(1.0, ref.abs().max().item())
