@@ -185,6 +185,15 @@ int64_t slim_eigh_workspace_bytes(int n);
  * A [n, n] (destroyed), one launch per column; Q [n, n] row-major, e holds n - 1 values, workspace of 5 n floats. */
 int slim_tridiagonalize_f32(float* A, int n, float* d, float* e, float* Q, void* workspace, int64_t workspace_bytes,
                             void* stream);
+/* `batch` reductions of equal size in ONE launch chain: A [batch][n, n], d / e [batch][n], Q [batch][n, n], workspace of
+ * 5 n floats per problem.  Several layers' fits share it (see slim_lowrank_fit_front / _back). */
+int slim_tridiagonalize_f32_batched(float* A, int n, int batch, float* d, float* e, float* Q, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+/* second stage for one problem: rocSOLVER stedc on (d, e) -- d becomes the eigenvalues, ascending -- and rows
+ * n-top .. n-1 of vecs [n, n] = eigenvectors of the `top` largest eigenvalues (Q times the tridiagonal ones).
+ * info: device status word.  workspace: n * n floats. */
+int slim_eigh_tail_f32(float* d, float* e, const float* Q, int n, int top, float* vecs, int32_t* info, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 int slim_eigh_f32(float* G, int n, int top, float* evals, int32_t* info, void* workspace, int64_t workspace_bytes,
                   void* stream);
 
@@ -217,6 +226,17 @@ int64_t slim_lowrank_fit_batched_workspace_bytes(int batch, int64_t N, int64_t K
 int slim_lowrank_fit_batched(const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
                              uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L,
                              float* S, int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* The fit in two halves around its l x l eigenproblem (no reference counterpart: the reference solves one torch.svd per
+ * layer, slim/lora.py:172).  front: up to the Rayleigh-Ritz matrix, written to M_out [l, l] fp32; *state (host int) goes
+ * to back unchanged, with the same workspace (slim_lowrank_fit_workspace_bytes) and sizes.  back: vecs [l, l] (row
+ * l-1-i = eigenvector of the i-th largest eigenvalue, i < r), evals [l] ascending, eig_info (device status word or
+ * NULL) -> U, Ut, L, S as slim_lowrank_fit returns them. */
+int slim_lowrank_fit_front(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter, uint32_t seed,
+                           int flags, int ns_steps, float* M_out, int32_t* state, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+int slim_lowrank_fit_back(int64_t N, int64_t K, int r, int l, int n_iter, const int32_t* state, const float* vecs,
+                          const float* evals, const int32_t* eig_info, const float* s, void* U, void* Ut, void* L, float* S,
+                          int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
  * N x K low-rank product itself) is written too when non-NULL; mask may be NULL (nothing zeroed). */

@@ -377,6 +377,49 @@ extern "C" int slim_tridiagonalize_f32(float* A, int n, float* d, float* e, floa
     return tridiagonalize(A, Q, ws, ws + 2 * n, ws + 4 * n, d, e, n, 1, (hipStream_t)stream);
 }
 
+// `batch` reductions in one launch chain: A [batch][n, n] (destroyed), d / e [batch][n], Q [batch][n, n]; workspace of
+// 5 n floats per problem.
+extern "C" int slim_tridiagonalize_f32_batched(float* A, int n, int batch, float* d, float* e, float* Q, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(A && d && e && Q && workspace && batch >= 1 && batch <= 65535, "slim_tridiagonalize_f32_batched: bad arguments");
+    SLIM_REQUIRE(n >= 3 && n <= SLIM_EIGH_MAX_N && n % 4 == 0, "slim_tridiagonalize_f32_batched: n must be a multiple of 4 in [4, 2048]");
+    SLIM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)Q % 16) == 0, "slim_tridiagonalize_f32_batched: buffers must be 16-byte aligned");
+    SLIM_REQUIRE(workspace_bytes >= (int64_t)5 * n * 4 * batch, "slim_tridiagonalize_f32_batched: workspace too small");
+    float* ws = (float*)workspace;
+    return tridiagonalize(A, Q, ws, ws + (int64_t)2 * n * batch, ws + (int64_t)4 * n * batch, d, e, n, batch, (hipStream_t)stream);
+}
+
+// Second stage for one problem: eigen-decomposition of tridiag(d, e) by rocSOLVER stedc (d becomes the eigenvalues,
+// ascending; e is destroyed) and rows n-top .. n-1 of vecs [n, n] = the eigenvectors of the `top` largest eigenvalues of
+// the original matrix (Q times the tridiagonal ones).  workspace: n * n floats.
+extern "C" int slim_eigh_tail_f32(float* d, float* e, const float* Q, int n, int top, float* vecs, int32_t* info, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(d && e && Q && vecs && info && workspace, "slim_eigh_tail_f32: null pointer");
+    SLIM_REQUIRE(n >= 3 && n <= SLIM_EIGH_MAX_N && top >= 1 && top <= n, "slim_eigh_tail_f32: bad sizes");
+    SLIM_REQUIRE(workspace_bytes >= (int64_t)n * n * 4, "slim_eigh_tail_f32: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    rb_handle h = nullptr;
+    int rc = solver_handle(st, &h);
+    if (rc) return rc;
+    SLIM_REQUIRE(g_solver.stedc && g_solver.sgemm, "slim_eigh_tail_f32: rocsolver_sstedc / rocblas_sgemm not available");
+    float* C = (float*)workspace;
+    {
+        SLIM_PROF("solver_stedc", st, 0.0, 4.0 * n * (double)n * n);
+        if (g_solver.stedc(h, RB_EVECT_TRIDIAGONAL, n, d, e, C, n, info) != 0) {
+            slim_set_error("rocsolver_sstedc failed");
+            return SLIM_ERR_SOLVER;
+        }
+    }
+    SLIM_PROF("eigh_backproduct", st, 0.0, 2.0 * n * (double)n * top);
+    const float one = 1.f, zero = 0.f;
+    const int64_t off = (int64_t)(n - top) * n;
+    if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, n, top, n, &one, Q, n, C + off, n, &zero, vecs + off, n) != 0) {
+        slim_set_error("rocblas_sgemm failed");
+        return SLIM_ERR_SOLVER;
+    }
+    return SLIM_OK;
+}
+
 extern "C" int64_t slim_eigh_workspace_bytes(int n) { return n > 0 ? slim_eigh_ws_bytes(n, 1) : 0; }
 
 // Eigenvalues (ascending) and the `top` leading eigenvectors of the symmetric matrix G [n, n] (fp32, both triangles

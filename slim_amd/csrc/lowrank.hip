@@ -562,11 +562,15 @@ extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t r
 // Every launch covers the whole batch (gridDim.z / strided-batched solver calls), so the launch count and the
 // length of the dependent chain are those of ONE fit.  Each problem's result is bit-identical to a single fit
 // wherever the solver's batched and single routines agree.
-extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l,
-                                        int n_iter, uint32_t seed, int flags, int ns_steps, const float* s, void* U,
-                                        void* Ut, void* L, float* S, int32_t* info_out, void* workspace,
-                                        int64_t workspace_bytes, void* stream) {
-    SLIM_REQUIRE(E && Et && U && L && workspace, "slim_lowrank_fit: null pointer");
+// phase FIT_ALL: the whole fit.  FIT_FRONT: up to the Rayleigh-Ritz matrix M (copied to M_ext), *state receives what
+// FIT_BACK needs to resume.  FIT_BACK: from the eigenvectors (rows of ext_vecs, ascending, as slim_eigh_f32 leaves them),
+// eigenvalues ext_evals and solver status ext_info of M to the factors.  Front and back share the workspace.
+enum { FIT_ALL = 0, FIT_FRONT = 1, FIT_BACK = 2 };
+static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
+                    uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S,
+                    int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream, float* M_ext, int* state,
+                    const float* ext_vecs, const float* ext_evals, const int* ext_info) {
+    SLIM_REQUIRE(workspace && (phase == FIT_BACK || (E && Et)) && (phase == FIT_FRONT || (U && L)), "slim_lowrank_fit: null pointer");
     SLIM_REQUIRE(batch >= 1 && batch <= 1024, "slim_lowrank_fit: batch must be in [1, 1024]");
     SLIM_REQUIRE(N > 0 && K > 0 && r > 0 && l >= r && n_iter >= 0, "slim_lowrank_fit: bad sizes");
     SLIM_REQUIRE(l <= N && l <= K, "slim_lowrank_fit: subspace dimension l exceeds min(N, K)");
@@ -578,7 +582,7 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     rb_handle h = nullptr;
     CHK(solver_handle(st, &h));
     FitWs w = fit_ws((char*)workspace, batch, N, K, l);
-    SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    if (phase != FIT_BACK) SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
     const bf16_t* Eb = (const bf16_t*)E;
     const bf16_t* Etb = (const bf16_t*)Et;
     const int64_t sE = N * K, sYn = N * l, sZk = K * l, sG = (int64_t)l * l;
@@ -599,6 +603,7 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
         return nt(batch, Qt, N, sYn, Etb, N, sE, l, (int)K, (int)N, nullptr, w.B[0].Xt, K, w.B[0].X, l, stream, sk_slab, sSk);
     };
 
+    if (phase != FIT_BACK) {
     // P0^T [l, K]: Gaussian test matrix;  Y = E P0;  Q = orth(Y)
     {
         const int64_t n = (int64_t)l * K;
@@ -628,7 +633,22 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     // Rayleigh-Ritz: B = Q^T E (kept as B^T = Z [K, l]); M = B B^T = W diag(S^2) W^T
     CHK(sketch_cols(w.A[a].Xt));
     CHK(gram(w.B[0].Xt, K, l, w, nullptr, stream));
-    if (!(flags & SLIM_FIT_LIBRARY_EIGH) && slim_eigh_supported(l) &&
+    if (phase == FIT_FRONT) {
+        SLIM_REQUIRE(batch == 1 && M_ext && state, "slim_lowrank_fit_front: bad arguments");
+        SLIM_HIP(hipMemcpyAsync(M_ext, w.G, (size_t)sG * sizeof(float), hipMemcpyDeviceToDevice, st));
+        *state = a | (ninfo << 8);
+        return SLIM_OK;
+    }
+    } else {
+        SLIM_REQUIRE(batch == 1 && state && ext_vecs && ext_evals, "slim_lowrank_fit_back: bad arguments");
+        a = *state & 0xff;
+        ninfo = *state >> 8;
+        SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS, "slim_lowrank_fit_back: bad state");
+        if (ext_info) SLIM_HIP(hipMemcpyAsync(w.info + ninfo, ext_info, sizeof(int), hipMemcpyDeviceToDevice, st));
+    }
+    if (phase == FIT_BACK) {
+        // the eigenproblem was solved outside (shared with other fits)
+    } else if (!(flags & SLIM_FIT_LIBRARY_EIGH) && slim_eigh_supported(l) &&
         slim_eigh_ws_bytes(l, batch) <= (int64_t)GRAM_MAX_SPLITS * l * l * 4 * batch) {
         // in-library solver (one launch per column); the split-K slab is free at this point and serves as its workspace
         CHK(slim_eigh_launch(w.G, l, batch, r, w.evals, w.info + ninfo, SLIM_FIT_INFO_WORDS, w.slab,
@@ -654,7 +674,8 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     ninfo += 1;
     {
         dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
-        top_eigvecs_kernel<<<grid, 256, 0, st>>>(w.G, w.evals, l, r, w.T16, S);
+        top_eigvecs_kernel<<<grid, 256, 0, st>>>(phase == FIT_BACK ? ext_vecs : w.G, phase == FIT_BACK ? ext_evals : w.evals, l, r,
+                                                 w.T16, S);
         SLIM_LAUNCH_CHECK();
     }
     // L = V_r S_r = B^T W_r  [K, r];  U = Q W_r  [N, r] (+ U^T = lora_right)
@@ -664,6 +685,33 @@ extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch
     if (info_out)
         SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
     return SLIM_OK;
+}
+
+extern "C" int slim_lowrank_fit_batched(const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l,
+                                        int n_iter, uint32_t seed, int flags, int ns_steps, const float* s, void* U,
+                                        void* Ut, void* L, float* S, int32_t* info_out, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    return fit_impl(FIT_ALL, E, Et, batch, N, K, r, l, n_iter, seed, flags, ns_steps, s, U, Ut, L, S, info_out, workspace,
+                    workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// The fit in two halves around its l x l eigenproblem, so that a caller compressing several layers at once can solve all
+// their eigenproblems' launch-bound first stage in ONE batched chain (slim_tridiagonalize_f32_batched) instead of one
+// 639-launch chain per layer.  front: everything up to the Rayleigh-Ritz matrix, written to M_out [l, l] fp32; *state
+// (host) is handed to back unchanged, with the same workspace and sizes.  back: vecs [l, l] (row l-1-i = eigenvector of
+// the i-th largest eigenvalue, i < r), evals [l] ascending, eig_info (device, solver status or NULL) -> the factors.
+extern "C" int slim_lowrank_fit_front(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,
+                                      uint32_t seed, int flags, int ns_steps, float* M_out, int32_t* state, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+    return fit_impl(FIT_FRONT, E, Et, 1, N, K, r, l, n_iter, seed, flags, ns_steps, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, workspace, workspace_bytes, stream, M_out, state, nullptr, nullptr, nullptr);
+}
+extern "C" int slim_lowrank_fit_back(int64_t N, int64_t K, int r, int l, int n_iter, const int32_t* state, const float* vecs,
+                                     const float* evals, const int32_t* eig_info, const float* s, void* U, void* Ut, void* L,
+                                     float* S, int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    int st_copy = state ? *state : -1;
+    return fit_impl(FIT_BACK, nullptr, nullptr, 1, N, K, r, l, n_iter, 0, 0, 0, s, U, Ut, L, S, info_out, workspace,
+                    workspace_bytes, stream, nullptr, &st_copy, vecs, evals, eig_info);
 }
 
 extern "C" int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,

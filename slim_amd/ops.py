@@ -371,6 +371,70 @@ def lora_prune_optimize(L32, R32, L_mask, T32, num_iters, lr, lr_end_factor, wan
     return losses[:num_iters] if want_losses else None
 
 
+def fit_flags(cholesky_qr=False, one_sided=False, library_eigh=False, exact_final=False, sketch_split=True):
+    return (int(bool(cholesky_qr)) | (2 if one_sided else 0) | (4 if library_eigh else 0) | (8 if exact_final else 0) |
+            (0 if sketch_split else 16))
+
+
+def fit_subspace(N, K, r, oversample):
+    """Subspace dimension l the fit uses for rank r (a multiple of 8 within min(N, K))."""
+    l = min(r + oversample, N, K)
+    return l - l % 8
+
+
+def lowrank_fit_front(E, Et, r, oversample, n_iter, M_out, seed=0, flags=0, ns_steps=0):
+    """First half of lowrank_fit: everything up to the l x l Rayleigh-Ritz matrix, which is written to M_out (fp32 [l, l]).
+    Returns the context lowrank_fit_back needs (it owns the workspace)."""
+    import ctypes
+    E = _chk(E, BF16, "E")
+    Et = _chk(Et, BF16, "Et")
+    M_out = _chk(M_out, torch.float32, "M_out")
+    N, K = E.shape
+    l = fit_subspace(N, K, r, oversample)
+    if r > l or tuple(M_out.shape) != (l, l):
+        raise ValueError("bad rank or Rayleigh-Ritz buffer")
+    state = ctypes.c_int32(-1)
+    ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", 1, N, K, l), E.device)
+    _lib.call("slim_lowrank_fit_front", _p(E), _p(Et), N, K, r, l, n_iter, seed, int(flags), int(ns_steps), _p(M_out),
+              ctypes.addressof(state), _p(ws), ws.numel(), _stream())
+    return dict(ws=ws, state=state, N=N, K=K, r=r, l=l, n_iter=n_iter, keep=(E, Et))
+
+
+def tridiagonalize_batched(A):
+    """A [B, n, n] symmetric fp32 (destroyed) -> d [B, n], e [B, n], Q [B, n, n] in one launch chain."""
+    A = _chk(A, torch.float32, "A")
+    B, n, _ = A.shape
+    d = torch.empty(B, n, dtype=torch.float32, device=A.device)
+    e = torch.empty(B, n, dtype=torch.float32, device=A.device)
+    Q = torch.empty(B, n, n, dtype=torch.float32, device=A.device)
+    ws = torch.empty(5 * n * B, dtype=torch.float32, device=A.device)
+    _lib.call("slim_tridiagonalize_f32_batched", _p(A), n, B, _p(d), _p(e), _p(Q), _p(ws), ws.numel() * 4, _stream())
+    return d, e, Q
+
+
+def lowrank_fit_back(ctx, d, e, Q, vecs, s=None):
+    """Second half: d, e, Q of the tridiagonalised Rayleigh-Ritz matrix (one problem) -> dict as lowrank_fit returns.
+    vecs: an [l, l] fp32 scratch buffer (the Rayleigh-Ritz matrix's own slot will do)."""
+    import ctypes
+    N, K, r, l = ctx["N"], ctx["K"], ctx["r"], ctx["l"]
+    dev = Q.device
+    d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
+    info1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws2 = torch.empty(l * l, dtype=torch.float32, device=dev)
+    _lib.call("slim_eigh_tail_f32", _p(d), _p(e), _p(Q), l, r, _p(vecs), _p(info1), _p(ws2), ws2.numel() * 4, _stream())
+    if s is not None:
+        s = _chk(s, torch.float32, "s")
+    U = torch.empty(N, r, dtype=BF16, device=dev)
+    Ut = torch.empty(r, N, dtype=BF16, device=dev)
+    L = torch.empty(K, r, dtype=BF16, device=dev)
+    S = torch.empty(r, dtype=torch.float32, device=dev)
+    info = torch.empty(64, dtype=torch.int32, device=dev)
+    ws = ctx["ws"]
+    _lib.call("slim_lowrank_fit_back", N, K, r, l, ctx["n_iter"], ctypes.addressof(ctx["state"]), _p(vecs), _p(d), _p(info1),
+              _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
+    return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
+
+
 def scale_rows(L, s):
     """In place: L[k, :] = bf16(L[k, :] / bf16(s[k])) (the division of lora_left by sqrt(scaler_row))."""
     L = _chk(L, BF16, "L")
