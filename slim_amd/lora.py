@@ -127,6 +127,77 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     return U, ops.transpose(U), L, info
 
 
+def _fit_kwargs(spread):
+    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_ONE_SIDED, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL, FIT_SKETCH_SPLIT),
+                ns_steps=fit_ns_steps(spread))
+
+
+def fit_plan(N, K, rank, outliers=None):
+    """(rank the randomized fit is asked for, oversampling, subspace dimension l, number t of deflated outlier columns)
+    of fit_error_matrix for these arguments; l is the size of the fit's eigenproblem."""
+    r8 = _round_up8(rank)
+    t = outliers[1] if outliers is not None else 0
+    if t == 0 or rank - t < 8:
+        rf, t = min(r8, min(N, K) - min(N, K) % 8), 0
+    else:
+        rf = _round_up8(rank - t)
+    over = max(FIT_MIN_OVERSAMPLE, rf // FIT_OVERSAMPLE_DIV)
+    return rf, over, ops.fit_subspace(N, K, rf, over), t
+
+
+def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out):
+    """fit_error_matrix up to the Rayleigh-Ritz matrix of its randomized fit (written to M_out [l, l], l from fit_plan), so
+    that the eigenproblems of several layers can share one batched tridiagonalisation.  Returns the state that
+    fit_error_matrix_back completes."""
+    N, K = E.shape
+    rf, over, l, t = fit_plan(N, K, rank, outliers)
+    p = dict(N=N, K=K, rank=rank, t=t, E=E)
+    if t == 0:
+        if rf != _round_up8(rank):
+            raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+        p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread))
+        return p
+    cols = outliers[0]
+    EO = torch.index_select(E, 1, cols).float()
+    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
+    EO[:, t:] = 0
+    EO = EO.to(torch.bfloat16).contiguous()
+    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
+    UO[:, t:] = 0
+    UOt[t:] = 0
+    _, C, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
+    E2 = ops.lowrank_residual(UO, Ct, E, None)
+    del C
+    p.update(UO=UO, Ct=Ct, info_o=info_o, E2=E2)
+    p["ctx"] = ops.lowrank_fit_front(E2, ops.transpose(E2), rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread))
+    return p
+
+
+def fit_error_matrix_back(p, d, e, Q, vecs, s):
+    """Second half of fit_error_matrix: (d, e, Q) = the tridiagonalised Rayleigh-Ritz matrix of this layer; returns what
+    fit_error_matrix returns, from the same arithmetic."""
+    N, K, rank, t = p["N"], p["K"], p["rank"], p["t"]
+    r8 = _round_up8(rank)
+    fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s)
+    if t == 0:
+        U, Ut, L = fit["U"], fit["Ut"], fit["L"]
+        if r8 != rank:
+            U[:, rank:] = 0
+            Ut[rank:] = 0
+            L[:, rank:] = 0
+        return U, Ut, L, fit["info"]
+    E = p["E"]
+    LO = ops.scale_rows(p["Ct"], s) if s is not None else p["Ct"]
+    U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
+    L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
+    U[:, :t] = p["UO"][:, :t]
+    U[:, t:rank] = fit["U"][:, :rank - t]
+    L[:, :t] = LO[:, :t]
+    L[:, t:rank] = fit["L"][:, :rank - t]
+    info = torch.cat([p["info_o"], fit["info"]])
+    return U, ops.transpose(U), L, info
+
+
 def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, ratio=OUTLIER_RATIO):
     """((indices of the outlier columns padded to a multiple of 8, number of real outliers) or None, spread of
     the remaining scales).  One host synchronisation; the driver precomputes the same quantities for a
@@ -289,6 +360,29 @@ def planned_group_key(module, rank_ratio, lora_tile_size, slim_lora, activations
     rank = min(lora_rank((N, K), rank_ratio, lora_tile_size), min(N, K))
     use_slim = bool(slim_lora) and not activations.has_zero
     return ((N, K), rank, use_slim, (not use_slim) or activations.outliers is None)
+
+
+def planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations):
+    """Size of the eigenproblem add_lora's fit will pose for this layer (needs activations.has_zero / .outliers), or None
+    when the shared eigen-solver does not take it."""
+    N, K = module.weight.shape
+    rank = min(lora_rank((N, K), rank_ratio, lora_tile_size), min(N, K))
+    use_slim = bool(slim_lora) and not activations.has_zero
+    l = fit_plan(N, K, rank, activations.outliers if use_slim else None)[2]
+    return l if (8 <= l <= 2048 and l < min(N, K) and not FIT_LIBRARY_EIGH) else None
+
+
+def add_lora_fit_front(c, M_out):
+    """Second phase, first half (see fit_error_matrix_front)."""
+    c.touch()
+    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out)
+
+
+def add_lora_fit_back(c, d, e, Q, vecs):
+    """Second phase, second half."""
+    c.touch()
+    c.fit = fit_error_matrix_back(c.pending, d, e, Q, vecs, c.s if c.separate else None)
+    c.pending = None
 
 
 def add_lora_fit(ctxs, E_group=None, Et_group=None):

@@ -36,6 +36,8 @@ COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "7"))
 # batched eigen-solver of rocSOLVER takes as long as the single ones one after the other, and separate fits
 # overlap their solver chains on different streams, which is faster as long as that solver is on the path.
 BATCH_FITS = os.environ.get("SLIM_BATCH_FITS", "0") == "1"
+# the eigenproblems of a block's fits share one batched tridiagonalisation chain (SLIM_SHARED_EIGH=0: every fit solves its own)
+SHARED_EIGH = os.environ.get("SLIM_SHARED_EIGH", "1") == "1"
 _side_streams = {}
 
 
@@ -326,6 +328,38 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
         ctxs[idx] = None
         return produced(lin)
 
+    if not buffers and SHARED_EIGH and separate_lora and not prune_lora and len(items) > 1:
+        # The fits of a block pose one l x l eigenproblem each, and its first stage (Householder tridiagonalisation) is a
+        # chain of l dependent launches: seven chains side by side take seven times the launches on four in-order
+        # hardware queues.  So the linears run to their Rayleigh-Ritz matrix on the side streams, ONE batched chain
+        # tridiagonalises all matrices of equal size, and the linears finish on the side streams again.
+        from . import lora as _lora
+        sizes = [_lora.planned_fit_l(lin, lora_rank, tile, slim_lora, wrapped) for _, lin, wrapped in items]
+        if all(l is not None for l in sizes):
+            slots, Mb = {}, {}
+            for idx, l in enumerate(sizes):
+                slots[idx] = (l, sum(1 for j in range(idx) if sizes[j] == l))
+            for l in set(sizes):
+                Mb[l] = torch.empty(sizes.count(l), l, l, dtype=torch.float32, device=dev)
+
+            def front(idx):
+                prepare(idx)
+                l, b = slots[idx]
+                _lora.add_lora_fit_front(ctxs[idx], Mb[l][b])
+                return ctxs[idx].tensors()
+
+            def back(idx, tri):
+                l, b = slots[idx]
+                d, e, Q = tri[l]
+                _lora.add_lora_fit_back(ctxs[idx], d[b], e[b], Q[b], Mb[l][b])
+                return finish(idx)
+
+            # (splitting the linears into two groups so that one group's chain overlaps the other's GEMM-heavy halves was
+            # measured slower, 56.7 vs 47 ms: the extra barriers cost more than the idle chip during the shared chain)
+            run_on_streams([lambda i=i: front(i) for i in range(len(items))], dev, n_streams)
+            tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
+            run_on_streams([lambda i=i: back(i, tri) for i in range(len(items))], dev, n_streams)
+            return
     if not buffers:
         # nothing to fit in lockstep: the three phases of a linear run back to back on one stream, so the
         # linears overlap freely (no barrier between the phases)
