@@ -127,8 +127,9 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     return U, ops.transpose(U), L, info
 
 
-def _fit_kwargs(spread):
-    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_ONE_SIDED, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL, FIT_SKETCH_SPLIT),
+def _fit_kwargs(spread, sketch_split=True):
+    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_ONE_SIDED, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL,
+                                                    FIT_SKETCH_SPLIT and sketch_split),
                 ns_steps=fit_ns_steps(spread))
 
 
@@ -145,7 +146,7 @@ def fit_plan(N, K, rank, outliers=None):
     return rf, over, ops.fit_subspace(N, K, rf, over), t
 
 
-def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out):
+def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=True):
     """fit_error_matrix up to the Rayleigh-Ritz matrix of its randomized fit (written to M_out [l, l], l from fit_plan), so
     that the eigenproblems of several layers can share one batched tridiagonalisation.  Returns the state that
     fit_error_matrix_back completes."""
@@ -155,7 +156,7 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out):
     if t == 0:
         if rf != _round_up8(rank):
             raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
-        p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread))
+        p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
         return p
     cols = outliers[0]
     EO = torch.index_select(E, 1, cols).float()
@@ -169,7 +170,7 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out):
     E2 = ops.lowrank_residual(UO, Ct, E, None)
     del C
     p.update(UO=UO, Ct=Ct, info_o=info_o, E2=E2)
-    p["ctx"] = ops.lowrank_fit_front(E2, ops.transpose(E2), rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread))
+    p["ctx"] = ops.lowrank_fit_front(E2, ops.transpose(E2), rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
     return p
 
 
@@ -372,10 +373,11 @@ def planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations):
     return l if (8 <= l <= 2048 and l < min(N, K) and not FIT_LIBRARY_EIGH) else None
 
 
-def add_lora_fit_front(c, M_out):
-    """Second phase, first half (see fit_error_matrix_front)."""
+def add_lora_fit_front(c, M_out, sketch_split=True):
+    """Second phase, first half (see fit_error_matrix_front).  sketch_split=False: the caller runs several fits side by
+    side, which fills the chip without cutting the sketch products along their reduction."""
     c.touch()
-    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out)
+    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out, sketch_split)
 
 
 def add_lora_fit_back(c, d, e, Q, vecs):

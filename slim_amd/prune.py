@@ -345,7 +345,7 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
             def front(idx):
                 prepare(idx)
                 l, b = slots[idx]
-                _lora.add_lora_fit_front(ctxs[idx], Mb[l][b])
+                _lora.add_lora_fit_front(ctxs[idx], Mb[l][b], sketch_split=len(items) < 3)
                 return ctxs[idx].tensors()
 
             def back(idx, tri):
