@@ -126,7 +126,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
     // load also waits for every earlier store's acknowledgement (a round trip to L2 per iteration): the common case
     // (no beta, no residual) therefore runs in a loop of its own that contains no global load at all, and the residual
     // form fetches all its W / mask pieces before its first store.
-    if (split || g.C32 || g.C16 || g.Wn) {
+    const bool wide16 = !split && g.C16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f && (g.ldc16 & 7) == 0 &&
+                        ((uintptr_t)g.C16 & 15) == 0;
+    if (wide16) {
+        // bf16 C alone (the tall products of the fit): 16-byte stores, eight columns per lane -- the store tail of a tile is
+        // bound by the number of store instructions, not by bytes
+        constexpr int TPR8 = BN / 8, RSTEP8 = 256 / TPR8, ITERS8 = BM / RSTEP8;
+        const int c = (t % TPR8) * 8, col = col0 + c, rt = t / TPR8;
+        const int nc = g.N - col;
+        if (nc > 0) {
+            float v[ITERS8][8];
+#pragma unroll
+            for (int it = 0; it < ITERS8; ++it)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[it][u] = T[(rt + it * RSTEP8) * TS + c + u] * g.alpha;
+#pragma unroll
+            for (int it = 0; it < ITERS8; ++it) {
+                const int row = row0 + rt + it * RSTEP8;
+                if (row >= g.M) continue;
+                bf16_t* p = g.C16 + (int64_t)row * g.ldc16 + col;
+                if (nc >= 8)
+                    *(u16x8*)p = u16x8{f32_to_bf16(v[it][0]), f32_to_bf16(v[it][1]), f32_to_bf16(v[it][2]), f32_to_bf16(v[it][3]),
+                                       f32_to_bf16(v[it][4]), f32_to_bf16(v[it][5]), f32_to_bf16(v[it][6]), f32_to_bf16(v[it][7])};
+                else
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < nc) p[u] = f32_to_bf16(v[it][u]);
+            }
+        }
+    } else if (split || g.C32 || g.C16 || g.Wn) {
         constexpr int TPR = BN / 4;                    // threads per tile row, four columns each
         constexpr int RSTEP = 256 / TPR, ITERS = BM / RSTEP;
         const int c = (t % TPR) * 4, col = col0 + c;
