@@ -401,7 +401,8 @@ static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, Fi
 // dst <- X G^(-1/2), G = X^T X: the polish of a basis that Newton-Schulz has already brought close to orthonormal
 // (eigenvalues of G within [0.46, 1.28]).  G^(-1/2) comes from the coupled Newton-Schulz iteration
 //     T = (3 I - Z Y) / 2,  Y <- Y T,  Z <- T Z,   Y0 = G, Z0 = I   (Y -> G^(1/2), Z -> G^(-1/2), error squared per step)
-// on the l x l matrices in fp32 (library GEMMs: three per step, a dozen microseconds each), which replaces the
+// on the l x l matrices in fp32 (library GEMMs: three per step, a dozen microseconds each; eight steps take an
+// eigenvalue of 0.01 to 0.997), which replaces the
 // Cholesky factorisation and triangular inversion of cholesky_qr (forty-odd solver launches, 1.6 ms at l = 640,
 // most of it in single-workgroup diagonal-block kernels).  A direction the iterate has lost entirely (eigenvalue
 // of G near zero) is not restored by this -- its column stays near zero and drops to the bottom of the
@@ -411,7 +412,7 @@ __global__ void scaled_identity_kernel(float* __restrict__ a, int l, float value
     if (j < l) a[(int64_t)blockIdx.z * l * l + (int64_t)i * l + j] = i == j ? value : 0.f;
 }
 
-#define POLISH_STEPS 5
+#define POLISH_STEPS 8
 static int invsqrt_qr(const Pair& src, const Pair& dst, int64_t rows, int l, FitWs& w, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     rb_handle h = nullptr;
@@ -516,10 +517,15 @@ static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int f
     if (!final_pass) return ns_orth(bufs, cur, rows, l, nq, 0, w, stream, out_idx);
     // last basis before the Rayleigh-Ritz step: the polynomial iteration leaves the singular values within [0.68, 1.13];
     // an fp32 inverse-square-root polish (or, on request, an exact Cholesky-QR) brings them to 1
+    // The polish converges only on a basis that is already well conditioned in EVERY direction (an eigenvalue x of the
+    // Gram matrix moves as x (3 - x)^2 / 4 per step), while nq steps are sized for the conditioning inside the leading
+    // subspace; on small layers, where l is a large part of min(N, K), the weakest directions of the last iterate are
+    // far below that.  Three more quintic steps (a factor 40 each way) before the polish cover them.
+    const bool exact = (flags & SLIM_FIT_EXACT_FINAL) != 0;
     int mid = cur;
-    CHK(ns_orth(bufs, cur, rows, l, nq, 0, w, stream, &mid));
+    CHK(ns_orth(bufs, cur, rows, l, exact ? nq : nq + 3, 0, w, stream, &mid));
     const int nxt = (mid + 1) % 3;
-    if (flags & SLIM_FIT_EXACT_FINAL) CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
+    if (exact) CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
     else CHK(invsqrt_qr(bufs[mid], bufs[nxt], rows, l, w, stream));
     *out_idx = nxt;
     return SLIM_OK;
