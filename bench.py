@@ -88,7 +88,7 @@ def cpu_baseline(seconds_budget=30.0):
 # kernel symbol (as a profiler prints it) of each family the in-library timer reports
 FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0,", "gemm_nt_small": "gemm_nt_kernel<1,", "gemm_nt_apply": "gemm_nt_kernel<2,",
                  "gemm_nt_sketch": "gemm_nt_kernel<3,", "gemm_nt_big": "gemm_nt_kernel<4,", "gemm_nt_residual": "gemm_nt_kernel<5,",
-                 "eigh_tridiag": "tridiag_step_kernel", "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
+                 "eigh_tridiag": "tridiag_step_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
                  "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel"}
 
 

@@ -750,16 +750,19 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     }
     SLIM_HIP(slim_allow_dynamic_lds((const void*)kernel, lds_bytes));
     const char* scope = names[fam];
-    SLIM_PROF(scope, stream,
-              2.0 * ((double)g.M + g.N) * g.Kd + (double)g.M * g.N * ((g.C32 ? 4.0 : 0.0) + (g.C16 ? 2.0 : 0.0) +
-                                                                      (g.Ct16 ? 2.0 : 0.0) + (g.Wn ? 5.0 : 0.0)),
-              2.0 * g.M * g.N * g.Kd * batch);
+    const double out_bytes = (double)g.M * g.N * ((g.C32 ? 4.0 : 0.0) + (g.C16 ? 2.0 : 0.0) + (g.Ct16 ? 2.0 : 0.0) + (g.Wn ? 5.0 : 0.0));
     if (g.splits > 1) {
         SLIM_REQUIRE(g.slab && !g.Wn && !(g.Ct16 && (g.C32 || g.beta != 0.f)),
                      "slim_gemm_nt_bf16: split-K supports C_f32 / C_bf16 outputs, or C_bf16 / C^T_bf16");
-        dim3 grid((unsigned)tiles, (unsigned)g.splits, (unsigned)batch);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, g);
-        SLIM_LAUNCH_CHECK();
+        {
+            // the product proper (its own scope, so that the scope's time per launch is the kernel's)
+            SLIM_PROF(scope, stream, 2.0 * ((double)g.M + g.N) * g.Kd + 4.0 * g.splits * (double)g.M * g.N,
+                      2.0 * g.M * g.N * g.Kd * batch);
+            dim3 grid((unsigned)tiles, (unsigned)g.splits, (unsigned)batch);
+            hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, g);
+            SLIM_LAUNCH_CHECK();
+        }
+        SLIM_PROF("splitk_reduce", stream, 4.0 * g.splits * (double)g.M * g.N + out_bytes);
         if (g.Ct16) {
             dim3 tgrid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)batch);
             SLIM_REQUIRE(tgrid.y <= 65535, "slim_gemm_nt_bf16: too many rows for the transposing reduction");
@@ -775,6 +778,7 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
         SLIM_LAUNCH_CHECK();
         return SLIM_OK;
     }
+    SLIM_PROF(scope, stream, 2.0 * ((double)g.M + g.N) * g.Kd + out_bytes, 2.0 * g.M * g.N * g.Kd * batch);
     hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, 1, (unsigned)batch), dim3(256), lds_bytes, (hipStream_t)stream, g);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
