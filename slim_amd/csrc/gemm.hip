@@ -22,20 +22,22 @@
 // keep more loads in flight per CU and fill the 256 CUs.
 // Variants 0-3 stage tiles through registers (one K-step ahead, padded LDS rows); 4+ use LDS-DMA, several stages deep.
 enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, DMA_128x128_S3, DMA_128x64_S3, DMA_64x128_S3, DMA_64x64_S4,
-       DMA_128x128_K32_S6, DMA_64x64_K32_S6, DMA_128x128_S4, TILE_COUNT };
-static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128};
-static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 128};
-static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64};
-static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 3, 3, 3, 4, 6, 6, 4};     // 0: register-staged
+       DMA_128x128_K32_S6, DMA_64x64_K32_S6, DMA_128x128_S4, TILE_128x128_K32, TILE_COUNT };
+static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 128};
+static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 128, 128};
+static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32};
+static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 3, 3, 3, 4, 6, 6, 4, 0};     // 0: register-staged
 
-template <int ROWS>
+// BKT elements of the reduction per tile row: BKT / 8 threads cover a row, 2048 / BKT rows per pass of the 256 threads
+template <int ROWS, int BKT>
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
-                                          u16x8 (&r)[ROWS / 32]) {
+                                          u16x8 (&r)[ROWS * BKT / 2048]) {
+    constexpr int TPR = BKT / 8, RPP = 256 / TPR;
     const int t = threadIdx.x;
-    const int kc = (t & 7) * 8;
+    const int kc = (t % TPR) * 8;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        int row = row0 + (t >> 3) + 32 * i;
+    for (int i = 0; i < ROWS / RPP; ++i) {
+        int row = row0 + (t / TPR) + RPP * i;
         row = row < rows ? row : rows - 1;
         const int k = k0 + kc;
         if (k < Kd) r[i] = *(const u16x8*)(P + (int64_t)row * ld + k);
@@ -46,14 +48,15 @@ __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int64_t 
     }
 }
 
-template <int ROWS>
-__device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[ROWS / 32]) {
+template <int ROWS, int BKT>
+__device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[ROWS * BKT / 2048]) {
+    constexpr int TPR = BKT / 8, RPP = 256 / TPR;
     const int t = threadIdx.x;
-    const int kc = (t & 7) * 8;
+    const int kc = (t % TPR) * 8;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int row = (t >> 3) + 32 * i;
-        *(u16x8*)(lds + row * LDS_STRIDE + kc) = r[i];
+    for (int i = 0; i < ROWS / RPP; ++i) {
+        const int row = (t / TPR) + RPP * i;
+        *(u16x8*)(lds + row * (BKT + 8) + kc) = r[i];
     }
 }
 
@@ -352,13 +355,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
 // FAMILY only names the instantiation (one symbol per shape class of the fit), so that a profiler's per-kernel
 // summary separates them the way the in-library timer does; the code is identical.
 enum { FAM_GRAM, FAM_SMALL, FAM_APPLY, FAM_SKETCH, FAM_BIG, FAM_RESIDUAL, FAM_COUNT };
-template <int FAMILY, int FM, int FN>
+template <int FAMILY, int FM, int FN, int BKT = 64>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
-    constexpr int BM = 32 * FM, BN = 32 * FN;
+    constexpr int BM = 32 * FM, BN = 32 * FN, STRIDE = BKT + 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    // buffer b: A tile at smem + b * (BM + BN) * LDS_STRIDE, B tile right after it
-    auto As = [&](int b) { return smem + b * (BM + BN) * LDS_STRIDE; };
-    auto Bs = [&](int b) { return smem + b * (BM + BN) * LDS_STRIDE + BM * LDS_STRIDE; };
+    // buffer b: A tile at smem + b * (BM + BN) * STRIDE, B tile right after it
+    auto As = [&](int b) { return smem + b * (BM + BN) * STRIDE; };
+    auto Bs = [&](int b) { return smem + b * (BM + BN) * STRIDE + BM * STRIDE; };
 
     int row0, col0;
     gemm_tile_origin<BM, BN>(g, row0, col0);
@@ -374,31 +377,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     gemm_stamp(g, 0);
-    u16x8 ra[BM / 32], rb[BN / 32];
-    const int nk_total = (g.Kd + BK - 1) / BK;
-    const int kt0 = g.splits > 1 ? (int)blockIdx.y * g.ksteps_per_split : 0;
-    const int nk = g.splits > 1 ? min(g.ksteps_per_split, nk_total - kt0) : nk_total;
-    load_tile<BM>(g.A, g.lda, g.M, g.Kd, row0, kt0 * BK, ra);
-    load_tile<BN>(g.B, g.ldb, g.N, g.Kd, col0, kt0 * BK, rb);
-    store_tile<BM>(As(0), ra);
-    store_tile<BN>(Bs(0), rb);
+    u16x8 ra[BM * BKT / 2048], rb[BN * BKT / 2048];
+    const int nk_total = (g.Kd + BKT - 1) / BKT;
+    const int per_split = g.ksteps_per_split * (BK / BKT);               // the plan counts 64-deep steps
+    const int kt0 = g.splits > 1 ? (int)blockIdx.y * per_split : 0;
+    const int nk = g.splits > 1 ? min(per_split, nk_total - kt0) : nk_total;
+    load_tile<BM, BKT>(g.A, g.lda, g.M, g.Kd, row0, kt0 * BKT, ra);
+    load_tile<BN, BKT>(g.B, g.ldb, g.N, g.Kd, col0, kt0 * BKT, rb);
+    store_tile<BM, BKT>(As(0), ra);
+    store_tile<BN, BKT>(Bs(0), rb);
     __syncthreads();
     gemm_stamp(g, 1);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<BM>(g.A, g.lda, g.M, g.Kd, row0, (kt0 + kt + 1) * BK, ra);
-            load_tile<BN>(g.B, g.ldb, g.N, g.Kd, col0, (kt0 + kt + 1) * BK, rb);
+            load_tile<BM, BKT>(g.A, g.lda, g.M, g.Kd, row0, (kt0 + kt + 1) * BKT, ra);
+            load_tile<BN, BKT>(g.B, g.ldb, g.N, g.Kd, col0, (kt0 + kt + 1) * BKT, rb);
         }
-        const bf16_t* a_base = As(cur) + (wr * 16 * FM + fr) * LDS_STRIDE + fq * 8;
-        const bf16_t* b_base = Bs(cur) + (wc * 16 * FN + fr) * LDS_STRIDE + fq * 8;
+        const bf16_t* a_base = As(cur) + (wr * 16 * FM + fr) * STRIDE + fq * 8;
+        const bf16_t* b_base = Bs(cur) + (wc * 16 * FN + fr) * STRIDE + fq * 8;
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
+        for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(a_base + i * 16 * LDS_STRIDE + ks * 32);
+            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(a_base + i * 16 * STRIDE + ks * 32);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(b_base + j * 16 * LDS_STRIDE + ks * 32);
+            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(b_base + j * 16 * STRIDE + ks * 32);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -406,8 +410,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            store_tile<BM>(As(cur ^ 1), ra);
-            store_tile<BN>(Bs(cur ^ 1), rb);
+            store_tile<BM, BKT>(As(cur ^ 1), ra);
+            store_tile<BN, BKT>(Bs(cur ^ 1), rb);
         }
         __syncthreads();
     }
@@ -681,6 +685,7 @@ static gemm_kernel_t gemm_kernel_of(int tile) {
         case DMA_128x128_K32_S6: return gemm_nt_glds_kernel<FAMILY, 4, 4, 32, 6>;
         case DMA_64x64_K32_S6: return gemm_nt_glds_kernel<FAMILY, 2, 2, 32, 6>;
         case DMA_128x128_S4: return gemm_nt_glds_kernel<FAMILY, 4, 4, 64, 4>;
+        case TILE_128x128_K32: return gemm_nt_kernel<FAMILY, 4, 4, 32>;
         default: return gemm_nt_kernel<FAMILY, 4, 4>;
     }
 }
@@ -727,7 +732,7 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
     const int loop_bytes = kTileStages[tile] ? kTileStages[tile] * (BM + BN) * kTileBK[tile] * (int)sizeof(bf16_t)
-                                             : 2 * (BM + BN) * LDS_STRIDE * (int)sizeof(bf16_t);
+                                             : 2 * (BM + BN) * (kTileBK[tile] + 8) * (int)sizeof(bf16_t);
     const int epilogue_bytes = BM * (BN + 1) * (int)sizeof(float);       // the output tile staged as fp32
     const int lds_bytes = loop_bytes > epilogue_bytes ? loop_bytes : epilogue_bytes;
     const int mx = g.M > g.N ? g.M : g.N, mn = g.M < g.N ? g.M : g.N;

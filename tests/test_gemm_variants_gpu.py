@@ -5,7 +5,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-N_VARIANTS = 11
+N_VARIANTS = 12
 SHAPES = [(128, 128, 64), (256, 384, 640), (200, 136, 72), (8, 8, 8), (640, 640, 520), (1000, 72, 1096), (64, 4096, 264),
           (130, 258, 2056)]
 
