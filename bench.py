@@ -121,8 +121,13 @@ def main():
     ap.add_argument("--rehearse-backend", default=None,
                     help="rehearsal of the multi-rank path on fewer GPUs than ranks: process-group backend (gloo); ranks "
                          "then share devices round-robin and the numbers mean nothing")
+    ap.add_argument("--gemm-family-tile", default="", help="tuning aid: family:tile[,family:tile...] (slim_gemm_set_family_tile)")
     ap.add_argument("--gemm-tile", type=int, default=-1, help="tuning aid: force one GEMM tile variant (slim_gemm_set_tile)")
+    ap.add_argument("--only", default="", help="tuning aid: comma-separated indices of the block's linears to keep (the line "
+                                               "printed then describes that subset, not the benchmark workload)")
     args = ap.parse_args()
+    if args.only:
+        LLAMA2_7B_BLOCK[:] = [LLAMA2_7B_BLOCK[int(i)] for i in args.only.split(",")]
 
     if os.environ.get("SLIM_BENCH_WATCHDOG"):        # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
@@ -203,6 +208,9 @@ def main():
         torch.cuda.synchronize()
 
     _lib.query("slim_gemm_set_tile", args.gemm_tile)
+    for item in filter(None, args.gemm_family_tile.split(",")):
+        fam, tile = item.split(":")
+        _lib.query("slim_gemm_set_family_tile", int(fam), int(tile))
     for _ in range(args.warmup):
         step()
     barrier()
@@ -280,7 +288,7 @@ def main():
             "metric": "weight GB/s compressed (bf16 in)", "value": value, "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "LLaMA-2-7B-shaped decoder block (7 linears, 0.405 GB bf16), SLiM recipe: wanda 2:4 + "
+            "config": {"workload": ("SUBSET %s (tuning run, not the benchmark workload) of: " % args.only if args.only else "") + "LLaMA-2-7B-shaped decoder block (7 linears, 0.405 GB bf16), SLiM recipe: wanda 2:4 + "
                                    "SLiM-Quant 4-bit + lora_rank 0.1 (r=512, tile 256), "
                                    f"{args.nsamples}x{args.seqlen} synthetic calibration activations resident in HBM",
                        "partition": f"layer-level over {world} rank(s)" + (" + RCCL broadcast of shards" if world > 1 else ""),

@@ -27,7 +27,9 @@ extern "C" {
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_ONE_SIDED 2   /* re-orthonormalise only the row-side iterate (once per full iteration) */
 #define SLIM_FIT_EXACT_FINAL 8  /* last basis finished by Cholesky-QR (rocSOLVER) instead of the fp32 inverse-square-root polish */
-#define SLIM_FIT_NO_SKETCH_SPLIT 16 /* never cut the sketch products along the reduction (by default the ones that under-fill the chip are) */
+#define SLIM_FIT_NO_SKETCH_SPLIT 16 /* the caller runs several fits side by side: do not cut the sketch products along the
+                                     * reduction (by default the ones that under-fill the chip are) and cut the Gram products
+                                     * into at most two slices */
 #define SLIM_FIT_LIBRARY_EIGH 4 /* Rayleigh-Ritz eigenproblem through rocSOLVER syevd instead of slim_eigh_f32's method */
 
 int slim_abi_version(void);
@@ -167,9 +169,14 @@ int slim_lora_prune_optimize(float* L, float* R, const uint8_t* L_mask, const fl
                              int num_iters, float lr, float lr_end_factor, float* losses, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
-/* Tuning aid: force the workgroup tile of every following GEMM launch in this process (0: 128x128, 1: 128x64,
- * 2: 64x128, 3: 64x64; anything else: chosen per problem, the default).  Results do not depend on the tile. */
+/* Tuning aid: force the workgroup tile of every following GEMM launch in this process (register-staged 0: 128x128,
+ * 1: 128x64, 2: 64x128, 3: 64x64, 11: 128x128 with 32-deep K-steps; LDS-DMA pipelines 4: 128x128 x 3 stages,
+ * 5: 128x64 x 3, 6: 64x128 x 3, 7: 64x64 x 4, 8: 128x128 K32 x 6, 9: 64x64 K32 x 6, 10: 128x128 x 4; anything else:
+ * chosen per shape family, the default).  Results do not depend on the tile. */
 void slim_gemm_set_tile(int tile);
+/* The same for one shape family (0: small output with a long reduction, 1: l x l x l, 2: tall x (l x l),
+ * 3: products with the error matrix, 4: large square, 5: residual); -1 restores the library's choice. */
+void slim_gemm_set_family_tile(int family, int tile);
 /* Tuning aid: while buf (device memory, 8 * capacity_workgroups int64) is set, every GEMM launch records, for each
  * workgroup below the capacity, 100 MHz timestamps of kernel entry, first tile staged, K-loop done and epilogue done.
  * NULL switches it off (the default). */
@@ -237,6 +244,15 @@ int slim_lowrank_fit_front(const void* E, const void* Et, int64_t N, int64_t K, 
 int slim_lowrank_fit_back(int64_t N, int64_t K, int r, int l, int n_iter, const int32_t* state, const float* vecs,
                           const float* evals, const int32_t* eig_info, const float* s, void* U, void* Ut, void* L, float* S,
                           int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* The two halves for `batch` same-shape fits in lockstep (operands strided as in slim_lowrank_fit_batched, workspace
+ * slim_lowrank_fit_batched_workspace_bytes; M_out and vecs [batch][l, l], evals [batch][l], eig_info [batch]). */
+int slim_lowrank_fit_front_batched(const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
+                                   uint32_t seed, int flags, int ns_steps, float* M_out, int32_t* state, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+int slim_lowrank_fit_back_batched(int batch, int64_t N, int64_t K, int r, int l, int n_iter, const int32_t* state,
+                                  const float* vecs, const float* evals, const int32_t* eig_info, const float* s, void* U,
+                                  void* Ut, void* L, float* S, int32_t* info_out, void* workspace, int64_t workspace_bytes,
+                                  void* stream);
 
 /* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
  * N x K low-rank product itself) is written too when non-NULL; mask may be NULL (nothing zeroed). */

@@ -14,7 +14,8 @@
 #include "gemm.hpp"
 
 #define BK 64
-#define LDS_STRIDE (BK + 8)
+#define LDS_PAD 16          // bf16 of padding per LDS row (SLIM_LDS_PAD at build time for experiments)
+#define LDS_STRIDE (BK + LDS_PAD)
 
 // Tile shapes: a 256-thread workgroup is 2 x 2 waves, a wave owns FM x FN fragments of 16 x 16, so the workgroup tile
 // is (32 FM) x (32 FN).  The big tile has the best reuse; the small ones exist because the products of the fit are
@@ -56,7 +57,7 @@ __device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[ROWS * 
 #pragma unroll
     for (int i = 0; i < ROWS / RPP; ++i) {
         const int row = (t / TPR) + RPP * i;
-        *(u16x8*)(lds + row * (BKT + 8) + kc) = r[i];
+        *(u16x8*)(lds + row * (BKT + LDS_PAD) + kc) = r[i];
     }
 }
 
@@ -357,7 +358,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
 enum { FAM_GRAM, FAM_SMALL, FAM_APPLY, FAM_SKETCH, FAM_BIG, FAM_RESIDUAL, FAM_COUNT };
 template <int FAMILY, int FM, int FN, int BKT = 64>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
-    constexpr int BM = 32 * FM, BN = 32 * FN, STRIDE = BKT + 8;
+    constexpr int BM = 32 * FM, BN = 32 * FN, STRIDE = BKT + LDS_PAD;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     // buffer b: A tile at smem + b * (BM + BN) * STRIDE, B tile right after it
     auto As = [&](int b) { return smem + b * (BM + BN) * STRIDE; };
@@ -706,10 +707,14 @@ extern "C" void slim_gemm_set_trace(void* buf, int capacity_workgroups) {
 // concurrent streams, where what counts is how long a product holds CU slots: there the 128 x 128 register-staged
 // tile is the cheapest for every shape class of the fit (measured on the whole compression step), so it is the default
 // and the other variants are reached through slim_gemm_set_tile.
-static int gemm_pick_tile(const GemmArgs& g, int batch) {
-    (void)g;
-    (void)batch;
-    return g_tile_override >= 0 ? g_tile_override : TILE_128x128;
+static int g_family_tile[FAM_COUNT] = {-1, -1, -1, -1, -1, -1};
+extern "C" void slim_gemm_set_family_tile(int family, int tile) {
+    if (family >= 0 && family < FAM_COUNT) g_family_tile[family] = (tile >= 0 && tile < TILE_COUNT) ? tile : -1;
+}
+
+static int gemm_pick_tile(int family) {
+    if (g_tile_override >= 0) return g_tile_override;
+    return g_family_tile[family] >= 0 ? g_family_tile[family] : TILE_128x128;
 }
 
 int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
@@ -727,14 +732,6 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                  "slim_gemm_nt_bf16: the polynomial epilogue writes C_bf16 only, of a square product");
     const int batch = g.batch > 1 ? g.batch : 1;
     SLIM_REQUIRE(batch <= 65535 && (batch == 1 || (!g.Wn && g.beta == 0.f)), "slim_gemm_nt_bf16: bad batch arguments");
-    const int tile = gemm_pick_tile(g, batch);
-    const int BM = kTileM[tile], BN = kTileN[tile];
-    const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
-    const int loop_bytes = kTileStages[tile] ? kTileStages[tile] * (BM + BN) * kTileBK[tile] * (int)sizeof(bf16_t)
-                                             : 2 * (BM + BN) * (kTileBK[tile] + 8) * (int)sizeof(bf16_t);
-    const int epilogue_bytes = BM * (BN + 1) * (int)sizeof(float);       // the output tile staged as fp32
-    const int lds_bytes = loop_bytes > epilogue_bytes ? loop_bytes : epilogue_bytes;
     const int mx = g.M > g.N ? g.M : g.N, mn = g.M < g.N ? g.M : g.N;
     const int fam = g.Wn ? FAM_RESIDUAL
                     : (mx <= 1536 && g.Kd > 1536) ? FAM_GRAM       // small output, long reduction
@@ -742,6 +739,14 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                     : (g.Kd <= 1536) ? FAM_APPLY                    // tall x (l x l)
                     : (mn <= 1536) ? FAM_SKETCH                     // (l x K) x (N x K)^T products with E
                     : FAM_BIG;
+    const int tile = gemm_pick_tile(fam);
+    const int BM = kTileM[tile], BN = kTileN[tile];
+    const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
+    const int loop_bytes = kTileStages[tile] ? kTileStages[tile] * (BM + BN) * kTileBK[tile] * (int)sizeof(bf16_t)
+                                             : 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
+    const int epilogue_bytes = BM * (BN + 1) * (int)sizeof(float);       // the output tile staged as fp32
+    const int lds_bytes = loop_bytes > epilogue_bytes ? loop_bytes : epilogue_bytes;
     static const char* const names[FAM_COUNT] = {"gemm_nt_gram", "gemm_nt_small", "gemm_nt_apply", "gemm_nt_sketch",
                                                  "gemm_nt_big", "gemm_nt_residual"};
     gemm_kernel_t kernel = nullptr;

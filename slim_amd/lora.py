@@ -174,6 +174,73 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
     return p
 
 
+def fit_error_matrix_front_group(Es, Ets, rank, outliers, spread, M_out, E_group, Et_group, sketch_split=True):
+    """fit_error_matrix_front for B same-shape layers in lockstep: Es / Ets are the layers' error matrices, outliers their
+    deflation sets (all with the same number of real outliers t), M_out [B, l, l].  E_group [B, N, K] / Et_group
+    [B, K, N] are the strided operands of the batched fit: with t == 0 they ARE the error matrices (Es[b] is E_group[b]),
+    otherwise they receive the deflated matrices.  Every member's result equals that of fit_error_matrix_front alone."""
+    B = len(Es)
+    N, K = Es[0].shape
+    rf, over, l, t = fit_plan(N, K, rank, outliers[0])
+    if any(fit_plan(N, K, rank, o)[3] != t for o in outliers):
+        raise ValueError("the layers of a group must deflate the same number of outlier columns")
+    p = dict(N=N, K=K, rank=rank, t=t, B=B, Es=Es)
+    if t == 0:
+        if rf != _round_up8(rank):
+            raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+        if any(Es[b].data_ptr() != E_group[b].data_ptr() or Ets[b].data_ptr() != Et_group[b].data_ptr() for b in range(B)):
+            raise ValueError("without deflation the error matrices must sit in the group's strided buffers")
+    else:
+        p["UO"], p["Ct"], p["info_o"] = [], [], []
+        for b in range(B):
+            cols = outliers[b][0]
+            EO = torch.index_select(Es[b], 1, cols).float()
+            EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
+            EO[:, t:] = 0
+            EO = EO.to(torch.bfloat16).contiguous()
+            UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
+            UO[:, t:] = 0
+            UOt[t:] = 0
+            _, C, Ct = ops.gemm_nt(UOt, Ets[b], out_bf16=True, out_t=True)
+            ops.lowrank_residual(UO, Ct, Es[b], None, out=E_group[b])
+            ops.transpose(E_group[b], out=Et_group[b])
+            del C
+            p["UO"].append(UO)
+            p["Ct"].append(Ct)
+            p["info_o"].append(info_o)
+    p["ctx"] = ops.lowrank_fit_front(E_group, Et_group, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
+    return p
+
+
+def fit_error_matrix_back_group(p, d, e, Q, vecs, ss, tail_info=None):
+    """Second half for a group: d, e [B, l], Q, vecs [B, l, l]; ss = per-layer scale vectors (or None).  Returns one
+    (U, Ut, L, info) per layer, as fit_error_matrix_back does.  tail_info: see ops.lowrank_fit_back."""
+    N, K, rank, t, B = p["N"], p["K"], p["rank"], p["t"], p["B"]
+    r8 = _round_up8(rank)
+    s = torch.stack(ss).contiguous() if ss is not None else None
+    fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s, tail_info=tail_info)
+    out = []
+    for b in range(B):
+        if t == 0:
+            U, Ut, L = fit["U"][b], fit["Ut"][b], fit["L"][b]
+            if r8 != rank:
+                U[:, rank:] = 0
+                Ut[rank:] = 0
+                L[:, rank:] = 0
+            out.append((U, Ut, L, fit["info"][b]))
+            continue
+        E = p["Es"][b]
+        LO = ops.scale_rows(p["Ct"][b], ss[b]) if ss is not None else p["Ct"][b]
+        U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
+        L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
+        U[:, :t] = p["UO"][b][:, :t]
+        U[:, t:rank] = fit["U"][b][:, :rank - t]
+        L[:, :t] = LO[:, :t]
+        L[:, t:rank] = fit["L"][b][:, :rank - t]
+        out.append((U, ops.transpose(U), L, torch.cat([p["info_o"][b], fit["info"][b]])))
+    return out
+
+
 def fit_error_matrix_back(p, d, e, Q, vecs, s):
     """Second half of fit_error_matrix: (d, e, Q) = the tridiagonalised Rayleigh-Ritz matrix of this layer; returns what
     fit_error_matrix returns, from the same arithmetic."""
@@ -371,6 +438,44 @@ def planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations):
     use_slim = bool(slim_lora) and not activations.has_zero
     l = fit_plan(N, K, rank, activations.outliers if use_slim else None)[2]
     return l if (8 <= l <= 2048 and l < min(N, K) and not FIT_LIBRARY_EIGH) else None
+
+
+def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations):
+    """(key, l) of a layer before it is prepared: layers with equal keys can run their fits in lockstep around the shared
+    eigen-solver (same shape, rank, number of deflated outlier columns and Newton-Schulz depth), l is the size of the
+    eigenproblem; None when the shared eigen-solver does not take the layer."""
+    l = planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations)
+    if l is None:
+        return None
+    N, K = module.weight.shape
+    rank = min(lora_rank((N, K), rank_ratio, lora_tile_size), min(N, K))
+    use_slim = bool(slim_lora) and not activations.has_zero
+    t = fit_plan(N, K, rank, activations.outliers if use_slim else None)[3]
+    spread = activations.scale_spread if use_slim else 1.0
+    return ((N, K), rank, use_slim, t, fit_ns_steps(spread)), l
+
+
+def add_lora_fit_front_group(ctxs, M_out, E_group, Et_group, sketch_split=True):
+    """Second phase, first half, for a group of layers with equal planned_fit_group keys (see
+    fit_error_matrix_front_group)."""
+    for c in ctxs:
+        c.touch()
+    if len({fit_ns_steps(c.spread) for c in ctxs}) != 1 or len({c.rank for c in ctxs}) != 1:
+        raise ValueError("the layers of a group must share rank and Newton-Schulz depth")
+    ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], ctxs[0].rank,
+                                                   [c.outliers for c in ctxs], ctxs[0].spread, M_out, E_group, Et_group,
+                                                   sketch_split)
+
+
+def add_lora_fit_back_group(ctxs, d, e, Q, vecs, tail_info=None):
+    """Second phase, second half, for the group add_lora_fit_front_group started."""
+    for c in ctxs:
+        c.touch()
+    ss = [c.s for c in ctxs] if (ctxs[0].separate and ctxs[0].s is not None) else None
+    fits = fit_error_matrix_back_group(ctxs[0].pending, d, e, Q, vecs, ss, tail_info)
+    ctxs[0].pending = None
+    for c, f in zip(ctxs, fits):
+        c.fit = f
 
 
 def add_lora_fit_front(c, M_out, sketch_split=True):

@@ -384,20 +384,25 @@ def fit_subspace(N, K, r, oversample):
 
 def lowrank_fit_front(E, Et, r, oversample, n_iter, M_out, seed=0, flags=0, ns_steps=0):
     """First half of lowrank_fit: everything up to the l x l Rayleigh-Ritz matrix, which is written to M_out (fp32 [l, l]).
+    E [B, N, K] (Et [B, K, N], M_out [B, l, l]) runs B same-shape fits in lockstep.
     Returns the context lowrank_fit_back needs (it owns the workspace)."""
     import ctypes
     E = _chk(E, BF16, "E")
     Et = _chk(Et, BF16, "Et")
     M_out = _chk(M_out, torch.float32, "M_out")
-    N, K = E.shape
+    batched = E.dim() == 3
+    B = E.shape[0] if batched else 1
+    N, K = E.shape[-2:]
+    if tuple(Et.shape) != ((B, K, N) if batched else (K, N)):
+        raise ValueError("Et must be the transpose of E")
     l = fit_subspace(N, K, r, oversample)
-    if r > l or tuple(M_out.shape) != (l, l):
+    if r > l or tuple(M_out.shape) != ((B, l, l) if batched else (l, l)):
         raise ValueError("bad rank or Rayleigh-Ritz buffer")
     state = ctypes.c_int32(-1)
-    ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", 1, N, K, l), E.device)
-    _lib.call("slim_lowrank_fit_front", _p(E), _p(Et), N, K, r, l, n_iter, seed, int(flags), int(ns_steps), _p(M_out),
-              ctypes.addressof(state), _p(ws), ws.numel(), _stream())
-    return dict(ws=ws, state=state, N=N, K=K, r=r, l=l, n_iter=n_iter, keep=(E, Et))
+    ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", B, N, K, l), E.device)
+    _lib.call("slim_lowrank_fit_front_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, int(flags), int(ns_steps),
+              _p(M_out), ctypes.addressof(state), _p(ws), ws.numel(), _stream())
+    return dict(ws=ws, state=state, N=N, K=K, r=r, l=l, n_iter=n_iter, keep=(E, Et), batch=B, batched=batched)
 
 
 def tridiagonalize_batched(A):
@@ -412,26 +417,55 @@ def tridiagonalize_batched(A):
     return d, e, Q
 
 
-def lowrank_fit_back(ctx, d, e, Q, vecs, s=None):
-    """Second half: d, e, Q of the tridiagonalised Rayleigh-Ritz matrix (one problem) -> dict as lowrank_fit returns.
-    vecs: an [l, l] fp32 scratch buffer (the Rayleigh-Ritz matrix's own slot will do)."""
+def eigh_tail(d, e, Q, vecs, top):
+    """Second stage of the eigen-solver for ONE problem: tridiagonal (d, e) [n] with the reduction's Q [n, n] -> eigenvalues
+    ascending in d, row n-1-i of vecs [n, n] = eigenvector of the i-th largest for i < top.  Returns the status word
+    (int32 [1] on the device, 0 = converged)."""
+    d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
+    n = d.numel()
+    if e.numel() != n or Q.numel() != n * n or vecs.numel() != n * n:
+        raise ValueError("eigh_tail: operands of one n x n problem expected")
+    info = torch.zeros(1, dtype=torch.int32, device=Q.device)
+    ws = torch.empty(n * n, dtype=torch.float32, device=Q.device)
+    _lib.call("slim_eigh_tail_f32", _p(d), _p(e), _p(Q), n, int(top), _p(vecs), _p(info), _p(ws), ws.numel() * 4, _stream())
+    return info
+
+
+def lowrank_fit_back(ctx, d, e, Q, vecs, s=None, tail_info=None):
+    """Second half: d, e, Q of the tridiagonalised Rayleigh-Ritz matrix (one problem, or [B, ...] for a context of B fits)
+    -> dict as lowrank_fit returns.  vecs: an [l, l] ([B, l, l]) fp32 scratch buffer (the Rayleigh-Ritz matrix's own
+    slot will do).  tail_info (int32 [B]): the caller has already run eigh_tail on every problem (d and vecs hold its
+    results) and passes the status words."""
     import ctypes
-    N, K, r, l = ctx["N"], ctx["K"], ctx["r"], ctx["l"]
+    N, K, r, l, B = ctx["N"], ctx["K"], ctx["r"], ctx["l"], ctx.get("batch", 1)
     dev = Q.device
     d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
-    info1 = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws2 = torch.empty(l * l, dtype=torch.float32, device=dev)
-    _lib.call("slim_eigh_tail_f32", _p(d), _p(e), _p(Q), l, r, _p(vecs), _p(info1), _p(ws2), ws2.numel() * 4, _stream())
+    if Q.numel() != B * l * l or vecs.numel() != B * l * l or d.numel() != B * l or e.numel() != B * l:
+        raise ValueError("eigen-solver operands do not match the fit context")
+    if tail_info is not None:
+        info1 = _chk(tail_info, torch.int32, "tail_info")
+        if info1.numel() != B:
+            raise ValueError("tail_info must hold one status word per problem")
+    else:
+        info1 = torch.zeros(B, dtype=torch.int32, device=dev)
+        ws2 = torch.empty(l * l, dtype=torch.float32, device=dev)
+        dv, ev, Qv, vv = d.reshape(B, l), e.reshape(B, l), Q.reshape(B, l, l), vecs.reshape(B, l, l)
+        for b in range(B):
+            _lib.call("slim_eigh_tail_f32", _p(dv[b]), _p(ev[b]), _p(Qv[b]), l, r, _p(vv[b]), _p(info1[b:]), _p(ws2),
+                      ws2.numel() * 4, _stream())
     if s is not None:
         s = _chk(s, torch.float32, "s")
-    U = torch.empty(N, r, dtype=BF16, device=dev)
-    Ut = torch.empty(r, N, dtype=BF16, device=dev)
-    L = torch.empty(K, r, dtype=BF16, device=dev)
-    S = torch.empty(r, dtype=torch.float32, device=dev)
-    info = torch.empty(64, dtype=torch.int32, device=dev)
+        if s.numel() != B * K:
+            raise ValueError("s must hold one scale per input channel (and per problem)")
+    lead = (B,) if ctx.get("batched") else ()
+    U = torch.empty(*lead, N, r, dtype=BF16, device=dev)
+    Ut = torch.empty(*lead, r, N, dtype=BF16, device=dev)
+    L = torch.empty(*lead, K, r, dtype=BF16, device=dev)
+    S = torch.empty(*lead, r, dtype=torch.float32, device=dev)
+    info = torch.empty(*lead, 64, dtype=torch.int32, device=dev)
     ws = ctx["ws"]
-    _lib.call("slim_lowrank_fit_back", N, K, r, l, ctx["n_iter"], ctypes.addressof(ctx["state"]), _p(vecs), _p(d), _p(info1),
-              _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
+    _lib.call("slim_lowrank_fit_back_batched", B, N, K, r, l, ctx["n_iter"], ctypes.addressof(ctx["state"]), _p(vecs), _p(d),
+              _p(info1), _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
 
@@ -443,7 +477,7 @@ def scale_rows(L, s):
     return L
 
 
-def lowrank_residual(U, L, W, mask, want_lr=False):
+def lowrank_residual(U, L, W, mask, want_lr=False, out=None):
     U = _chk(U, BF16, "U")
     L = _chk(L, BF16, "L")
     W = _chk(W, BF16, "W")
@@ -451,7 +485,9 @@ def lowrank_residual(U, L, W, mask, want_lr=False):
         mask = _chk(mask, torch.bool, "mask")
     N, K = W.shape
     r = U.shape[1]
-    Wn = torch.empty_like(W)
+    if out is not None and (out.dtype != BF16 or tuple(out.shape) != tuple(W.shape) or not out.is_contiguous()):
+        raise ValueError("out must be a contiguous bf16 tensor of W's shape")
+    Wn = torch.empty_like(W) if out is None else out
     LR = torch.empty_like(W) if want_lr else None
     _lib.call("slim_lowrank_residual", _p(U), _p(L), N, K, r, _p(W), _p(mask), _p(Wn), _p(LR), _stream())
     return (Wn, LR) if want_lr else Wn

@@ -38,6 +38,13 @@ COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "7"))
 BATCH_FITS = os.environ.get("SLIM_BATCH_FITS", "0") == "1"
 # the eigenproblems of a block's fits share one batched tridiagonalisation chain (SLIM_SHARED_EIGH=0: every fit solves its own)
 SHARED_EIGH = os.environ.get("SLIM_SHARED_EIGH", "1") == "1"
+# with the shared eigen-solver: linears of a block with the same shape and input statistics (q/k/v, gate/up) run their fits
+# as one lockstep chain (SLIM_GROUP_FITS=0: one chain per linear)
+GROUP_FITS = os.environ.get("SLIM_GROUP_FITS", "1") == "1"
+GROUP_MAX = int(os.environ.get("SLIM_GROUP_MAX", "0"))
+# which of the side streams carry the chains when there are at most that many: HIP spreads a process's streams over four
+# in-order hardware queues, and these four of the seven side streams sit on four different ones
+GROUP_STREAM_IDS = [int(x) for x in os.environ.get("SLIM_GROUP_STREAMS", "0,1,2,6").split(",") if x != ""]
 _side_streams = {}
 
 
@@ -79,7 +86,7 @@ STREAM_THREADS = os.environ.get("SLIM_STREAM_THREADS", "1") != "0"
 LAST_STREAM_TRACE = []
 
 
-def run_on_streams(jobs, dev, n_streams=None):
+def run_on_streams(jobs, dev, n_streams=None, stream_ids=None):
     """Run independent GPU jobs (callables that only enqueue work and return the tensors they produced) on side
     streams that start after the current stream's pending work; the current stream then waits for all of them.
 
@@ -93,7 +100,11 @@ def run_on_streams(jobs, dev, n_streams=None):
         for job in jobs:
             job()
         return
-    streams = _streams_for(dev, min(n, len(jobs)))
+    if stream_ids and len(jobs) <= len(stream_ids) and max(stream_ids) < n:
+        pool = _streams_for(dev, n)            # a chosen subset of the full set of side streams
+        streams = [pool[i] for i in stream_ids[:len(jobs)]]
+    else:
+        streams = _streams_for(dev, min(n, len(jobs)))
     trace = STREAM_TRACE
     ev = torch.cuda.Event(enable_timing=trace)
     ev.record(main)
@@ -334,31 +345,81 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
         # hardware queues.  So the linears run to their Rayleigh-Ritz matrix on the side streams, ONE batched chain
         # tridiagonalises all matrices of equal size, and the linears finish on the side streams again.
         from . import lora as _lora
-        sizes = [_lora.planned_fit_l(lin, lora_rank, tile, slim_lora, wrapped) for _, lin, wrapped in items]
-        if all(l is not None for l in sizes):
-            slots, Mb = {}, {}
-            for idx, l in enumerate(sizes):
-                slots[idx] = (l, sum(1 for j in range(idx) if sizes[j] == l))
-            for l in set(sizes):
-                Mb[l] = torch.empty(sizes.count(l), l, l, dtype=torch.float32, device=dev)
+        plans = [_lora.planned_fit_group(lin, lora_rank, tile, slim_lora, wrapped) for _, lin, wrapped in items]
+        if all(p is not None for p in plans):
+            # linears with equal plans (q/k/v and gate/up of a LLaMA block: same shape, same input statistics) run as ONE
+            # lockstep chain whose launches carry the whole group; the others are chains of their own
+            fit_groups = {}
+            seen = {}
+            for idx, (key, l) in enumerate(plans):
+                n_seen = seen.get((key, l), 0)
+                seen[(key, l)] = n_seen + 1
+                part = n_seen // GROUP_MAX if GROUP_MAX > 0 else 0          # at most GROUP_MAX members per chain
+                fit_groups.setdefault((key, l, part) if GROUP_FITS else (key, l, idx), []).append(idx)
+            fit_groups = list(fit_groups.items())
+            count, where, gbuf = {}, [], []
+            for gkey, members in fit_groups:
+                l = gkey[1]
+                where.append((l, count.get(l, 0)))
+                count[l] = count.get(l, 0) + len(members)
+                (N, K), t = gkey[0][0], gkey[0][3]
+                gbuf.append((torch.empty(len(members), N, K, dtype=torch.bfloat16, device=dev),
+                             torch.empty(len(members), K, N, dtype=torch.bfloat16, device=dev), t)
+                            if len(members) > 1 else None)
+            Mb = {l: torch.empty(n, l, l, dtype=torch.float32, device=dev) for l, n in count.items()}
+            split = len(items) < 3          # fewer fits than that do not fill the chip by themselves
 
-            def front(idx):
-                prepare(idx)
-                l, b = slots[idx]
-                _lora.add_lora_fit_front(ctxs[idx], Mb[l][b], sketch_split=len(items) < 3)
-                return ctxs[idx].tensors()
+            def prepare_into(idx, E_out, Et_out):
+                name, lin, wrapped = items[idx]
+                if describe:
+                    describe(name)
+                ctxs[idx] = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
+                                             separate_lora, tile, quantize_first, scale_important_weights, E_out, Et_out)
 
-            def back(idx, tri):
-                l, b = slots[idx]
+            def front(g):
+                members = fit_groups[g][1]
+                l, b0 = where[g]
+                if gbuf[g] is None:
+                    prepare_into(members[0], None, None)
+                    _lora.add_lora_fit_front(ctxs[members[0]], Mb[l][b0], sketch_split=split)
+                else:
+                    Eg, Etg, t = gbuf[g]
+                    for b, idx in enumerate(members):       # without deflation the error matrices are the strided operands
+                        prepare_into(idx, Eg[b] if t == 0 else None, Etg[b] if t == 0 else None)
+                    _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], Eg, Etg,
+                                                   sketch_split=split)
+                return [x for i in members for x in ctxs[i].tensors()] + ([gbuf[g][0], gbuf[g][1]] if gbuf[g] else [])
+
+            def back(g, tri):
+                members = fit_groups[g][1]
+                l, b0 = where[g]
                 d, e, Q = tri[l]
-                _lora.add_lora_fit_back(ctxs[idx], d[b], e[b], Q[b], Mb[l][b])
-                return finish(idx)
+                if gbuf[g] is None:
+                    _lora.add_lora_fit_back(ctxs[members[0]], d[b0], e[b0], Q[b0], Mb[l][b0])
+                else:
+                    sl = slice(b0, b0 + len(members))
+                    _lora.add_lora_fit_back_group([ctxs[i] for i in members], d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
+                return [x for i in members for x in ctxs[i].tensors()]
+
+            def tail(g, b, tri):
+                # the second stage of a grouped member's eigen-solve (a library call per problem): one job per member, so
+                # that the members' solves overlap instead of queueing on their group's stream
+                l, b0 = where[g]
+                d, e, Q = tri[l]
+                r_fit = ctxs[fit_groups[g][1][0]].pending["ctx"]["r"]
+                tails[l][b0 + b:b0 + b + 1] = ops.eigh_tail(d[b0 + b], e[b0 + b], Q[b0 + b], Mb[l][b0 + b], r_fit)
+                return [tails[l]]
 
             # (splitting the linears into two groups so that one group's chain overlaps the other's GEMM-heavy halves was
             # measured slower, 56.7 vs 47 ms: the extra barriers cost more than the idle chip during the shared chain)
-            run_on_streams([lambda i=i: front(i) for i in range(len(items))], dev, n_streams)
+            ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
+            run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
-            run_on_streams([lambda i=i: back(i, tri) for i in range(len(items))], dev, n_streams)
+            tails = {l: torch.zeros(n, dtype=torch.int32, device=dev) for l, n in count.items()}
+            run_on_streams([lambda g=g, b=b: tail(g, b, tri) for g in range(len(fit_groups)) if gbuf[g] is not None
+                            for b in range(len(fit_groups[g][1]))], dev, n_streams)
+            run_on_streams([lambda g=g: back(g, tri) for g in range(len(fit_groups))], dev, n_streams, ids)
+            run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
             return
     if not buffers:
         # nothing to fit in lockstep: the three phases of a linear run back to back on one stream, so the

@@ -38,3 +38,82 @@ def test_split_fit_equals_single_call():
         for k in ("U", "Ut", "L"):
             assert torch.equal(got[k], refs[i][k]), (i, k)
         torch.testing.assert_close(got["S"], refs[i]["S"], rtol=0, atol=0)
+
+
+def test_batched_split_fit_equals_single_call():
+    """Three same-shape fits in lockstep through the batched halves: every member equals its single-call fit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slim_amd import ops
+    from slim_amd.lora import FIT_ITERS
+    r, over, N, K, B = 64, 64, 768, 1024, 3
+    Eg = torch.empty(B, N, K, dtype=torch.bfloat16, device="cuda")
+    Etg = torch.empty(B, K, N, dtype=torch.bfloat16, device="cuda")
+    ss, refs = [], []
+    for i in range(B):
+        W = synth_weight(N, K, 270 + i)
+        sr = O.shift_zeros(synth_scaler(K, 280 + i))
+        mask = O.prune_nm(O.saliency(W, sr), 2, 4)
+        Eg[i] = O.add_lora(W, mask, sr, 0.1, tile=None)["error_mat"].to(torch.bfloat16).cuda()
+        Etg[i] = Eg[i].t()
+        ss.append(torch.sqrt(sr).cuda())
+        refs.append(ops.lowrank_fit(Eg[i], Etg[i], r, over, FIT_ITERS, seed=0, s=ss[i]))
+    l = ops.fit_subspace(N, K, r, over)
+    Mb = torch.empty(B, l, l, dtype=torch.float32, device="cuda")
+    ctx = ops.lowrank_fit_front(Eg, Etg, r, over, FIT_ITERS, Mb, seed=0)
+    d, e, Q = ops.tridiagonalize_batched(Mb)
+    got = ops.lowrank_fit_back(ctx, d, e, Q, Mb, s=torch.stack(ss))
+    torch.cuda.synchronize()
+    assert int(got["info"].abs().sum()) == 0
+    for i in range(B):
+        for k in ("U", "Ut", "L"):
+            assert torch.equal(got[k][i], refs[i][k]), (i, k)
+        torch.testing.assert_close(got["S"][i], refs[i]["S"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("outlier_gain", [1.0, 300.0])
+def test_group_fits_equal_separate_fits(outlier_gain):
+    """compress_linears with the same-input linears of a block fitted as one lockstep group, as separate chains around the
+    shared eigen-solver, and with one eigen-solve per fit: identical layers.  With outlier channels in the shared input
+    the grouped members deflate them before the lockstep fit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import slim_amd.prune as P
+    from slim_amd import ops
+    from slim_amd.layerwrapper import WrappedGPT
+    from slim_amd.quantization.quantization import Quantizer
+    dev = torch.device("cuda", 0)
+
+    import slim_amd.lora as LR
+
+    def run(shared, grouped):
+        # (the driver cuts the sketch products along their reduction only when fewer than three chains run side by side,
+        # which changes rounding: switched off here so that all three modes do the same arithmetic)
+        old = P.SHARED_EIGH, P.GROUP_FITS, LR.FIT_SKETCH_SPLIT
+        P.SHARED_EIGH, P.GROUP_FITS, LR.FIT_SKETCH_SPLIT = shared, grouped, False
+        try:
+            X = synth_weight(256, 1024, 300, sigma=1.0)
+            X[:, [5, 77, 900]] *= outlier_gain
+            X2 = synth_weight(256, 512, 301, sigma=1.0)
+            items = []
+            for i, (n, k, x) in enumerate([(512, 1024, X), (512, 1024, X), (512, 1024, X), (1024, 512, X2), (768, 1024, X)]):
+                lin = torch.nn.Linear(k, n, bias=False, device=dev, dtype=torch.bfloat16)
+                lin.weight.data = synth_weight(n, k, 310 + i).to(dev)
+                wr = WrappedGPT(lin)
+                wr.add_batch(x.to(dev).reshape(1, *x.shape), None)
+                wr.scaler_row = ops.shift_zeros(wr.scaler_row)
+                items.append((f"l{i}", lin, wr))
+            P.compress_linears(items, dev, 2, 4, quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
+                               lora_rank=0.1, slim_lora=True)
+            torch.cuda.synchronize()
+            if outlier_gain > 1:
+                assert items[0][2].outliers is not None and items[0][2].outliers[1] == 3
+            return [(lin.weight.data.clone(), lin.lora_left.data.clone(), lin.lora_right.data.clone()) for _, lin, _ in items]
+        finally:
+            P.SHARED_EIGH, P.GROUP_FITS, LR.FIT_SKETCH_SPLIT = old
+
+    base = run(False, False)
+    for shared, grouped in ((True, False), (True, True)):
+        other = run(shared, grouped)
+        for i, (a, b) in enumerate(zip(base, other)):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), (shared, grouped, i)

@@ -12,17 +12,21 @@ orig = P.run_on_streams
 calls = []
 
 
-def traced(jobs, dev, n_streams=None):
-    orig(jobs, dev, n_streams)
+def traced(jobs, dev, n_streams=None, stream_ids=None):
+    orig(jobs, dev, n_streams, stream_ids)
     if P.LAST_STREAM_TRACE:
         calls.append(list(P.LAST_STREAM_TRACE))
 
 
 P.run_on_streams = traced
+if "--only" in sys.argv:                      # e.g. --only 0,1,2,3: the timeline of a subset of the block's linears
+    k = sys.argv.index("--only")
+    keep = [int(x) for x in sys.argv[k + 1].split(",")]
+    B.LLAMA2_7B_BLOCK[:] = [B.LLAMA2_7B_BLOCK[i] for i in keep]
+    del sys.argv[k:k + 2]
 sys.argv = [sys.argv[0], "--no-cpu-baseline", "--steps", "1", "--warmup", "1"] + sys.argv[1:]
 B.main()
-last = [c for c in calls if len(c) == 7][-2]          # the last multi-stream step (the final call is the single-stream one)
-names = [x[0] for x in B.LLAMA2_7B_BLOCK]
-for r in last:
-    print(f"{names[r['job']]:<10} stream {r['stream']}  host enqueue {r['host_start_ms']:6.2f} -> {r['host_end_ms']:6.2f} ms   "
-          f"gpu {r['gpu_start_ms']:6.2f} -> {r['gpu_end_ms']:6.2f} ms", file=sys.stderr)
+# every run_on_streams call of the run, in order (jobs are linears, or groups of linears in the grouped phases)
+for k, c in enumerate(calls):
+    print(f"-- call {k}: {len(c)} jobs; gpu spans (ms): " +
+          "  ".join(f"{r['gpu_start_ms']:.2f}-{r['gpu_end_ms']:.2f}" for r in c), file=sys.stderr)
