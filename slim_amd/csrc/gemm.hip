@@ -75,7 +75,16 @@ __device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, int& row0, int& co
     // served by L2
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     int tm, tn;
-    if (tiles_m < tiles_n) {
+    if (g.sym) {
+        // tiles on and above the diagonal, row by row: row tm holds tiles_n - tm of them
+        tm = 0;
+        int rest = wgid;
+        while (rest >= tiles_n - tm) {
+            rest -= tiles_n - tm;
+            ++tm;
+        }
+        tn = tm + rest;
+    } else if (tiles_m < tiles_n) {
         tn = wgid / tiles_m;
         tm = wgid % tiles_m;
     } else {
@@ -583,16 +592,18 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
 // C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n, int N, float alpha, float beta,
                                      float* __restrict__ C32, int64_t ldc32, bf16_t* __restrict__ C16, int64_t ldc16,
-                                     int64_t sSlab, int64_t sC32, int64_t sC16) {
+                                     int64_t sSlab, int64_t sC32, int64_t sC16, int sym_tile) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t bz = blockIdx.y;          // strided batch
     slab += bz * sSlab;
     if (C32) C32 += bz * sC32;
     if (C16) C16 += bz * sC16;
-    float acc = 0.f;
-    for (int z = 0; z < splits; ++z) acc += slab[(int64_t)z * n + i];
     const int64_t row = i / N, col = i - row * N;
+    // symmetric products fill only the tiles on and above the diagonal: below it, read the mirrored element
+    const int64_t src = (sym_tile && row / sym_tile > col / sym_tile) ? col * N + row : i;
+    float acc = 0.f;
+    for (int z = 0; z < splits; ++z) acc += slab[(int64_t)z * n + src];
     float v = acc * alpha;
     if (C32) {
         if (beta != 0.f) v += beta * C32[row * ldc32 + col];
@@ -741,7 +752,9 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                     : FAM_BIG;
     const int tile = gemm_pick_tile(fam);
     const int BM = kTileM[tile], BN = kTileN[tile];
-    const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    if (g.sym && !(g.splits > 1 && g.M == g.N && BM == BN && g.A == g.B && g.lda == g.ldb && !g.Ct16)) g.sym = 0;
+    const int64_t tiles_m = (g.M + BM - 1) / BM;
+    const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
     const int loop_bytes = kTileStages[tile] ? kTileStages[tile] * (BM + BN) * kTileBK[tile] * (int)sizeof(bf16_t)
                                              : 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
@@ -784,7 +797,7 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
         const int64_t n = (int64_t)g.M * g.N;
         dim3 rgrid((unsigned)ceil_div64(n, 256), (unsigned)batch);
         splitk_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32,
-                                                                     g.C16, g.ldc16, g.sSlab, g.sC32, g.sC16);
+                                                                     g.C16, g.ldc16, g.sSlab, g.sC32, g.sC16, g.sym ? BM : 0);
         SLIM_LAUNCH_CHECK();
         return SLIM_OK;
     }
@@ -818,6 +831,7 @@ extern "C" int slim_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* 
     g.ksteps_per_split = (nk + splits - 1) / splits;
     g.splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     g.slab = slab;
+    g.sym = (A == Bt && lda == ldb && M == N);      // X X^T: the tiles below the diagonal are mirrored, not recomputed
     return slim_gemm_launch(g, stream);
 }
 

@@ -26,6 +26,10 @@ struct GemmArgs {
     // (no other output), summed afterwards in slice order by splitk_reduce_kernel
     int splits = 0, ksteps_per_split = 0;
     float* slab = nullptr;
+    // symmetric product (A == B, M == N, split-K only): workgroups cover the tiles on and above the diagonal, and the
+    // reduction reads the mirrored element for the tiles below it (X^T X computed once per pair of tiles; the mirrored
+    // value is what the lower tile would have produced, since every product of the sum commutes)
+    int sym = 0;
     // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
     int batch = 1;
     int64_t sA = 0, sB = 0, sC32 = 0, sC16 = 0, sCt = 0, sSlab = 0;

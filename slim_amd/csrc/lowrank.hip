@@ -350,6 +350,7 @@ static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, vo
     g.sC32 = g.sC16 = (int64_t)l * l;
     g.slab = w.slab;
     g.sSlab = (int64_t)GRAM_MAX_SPLITS * l * l;
+    g.sym = 1;          // honoured when the product is cut along the reduction (the reduction mirrors the lower tiles)
     gemm_plan_splits(g, splits);
     return slim_gemm_launch(g, stream);
 }

@@ -44,3 +44,19 @@ def test_gemm_variant_matches_reference(variant):
             T16, Tt = ops.gemm_nt_splitk_t(A, Bt, splits=3, alpha=0.5)
             assert torch.equal(Tt, T16.t()), (variant, M, N, Kd, "split, transposed")
             assert (T16.double() - 0.5 * ref).abs().max().item() <= (tol + 2 ** -8) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,kd,splits", [(504, 4096, 2), (640, 1032, 4), (128, 512, 2), (200, 2048, 16)])
+def test_symmetric_splitk_equals_full_product(n, kd, splits):
+    """X X^T through the split-K entry point computes the tiles on and above the diagonal and mirrors the rest: the
+    result is bit-identical to the same product with the second operand passed as a separate copy (all tiles computed)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slim_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(n + kd)
+    X = torch.randn(n, kd, generator=g, device="cuda").to(torch.bfloat16)
+    full32, full16 = ops.gemm_nt_splitk(X, X.clone(), splits)
+    sym32, sym16 = ops.gemm_nt_splitk(X, X, splits)
+    torch.cuda.synchronize()
+    assert torch.equal(sym32, full32) and torch.equal(sym16, full16)
+    assert torch.equal(sym32, sym32.t())
