@@ -94,8 +94,8 @@ FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0,", "gemm_nt_small": "gemm_nt_
 
 def measured_traffic(family):
     """HBM bytes per launch of a kernel family from the committed PMC measurement of this same command
-    (profiles/r1d_pmc_traffic.json, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_pmc_traffic.json")
+    (profiles/r1e_pmc_traffic.json, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1e_pmc_traffic.json")
     sym = FAMILY_KERNEL.get(family)
     if sym is None or not os.path.exists(path):
         return None
@@ -241,6 +241,20 @@ def main():
         barrier()
         prof_single = _lib.profile_summary()
         _lib.profile_enable(False)
+    # The launches of the timed configuration carry one to four problems (same-input linears fitted in lockstep); the
+    # counter replay behind `traffic` issues problems one by one.  One more single-stream step with the lockstep groups
+    # off counts the problems per family, which turns the measured bytes per problem into bytes per launch.
+    prof_problems = None
+    if world == 1:
+        import slim_amd.prune as _P
+        grouped = _P.GROUP_FITS
+        _P.GROUP_FITS = False
+        _lib.profile_enable(True)
+        step(1)
+        barrier()
+        prof_problems = _lib.profile_summary()
+        _lib.profile_enable(False)
+        _P.GROUP_FITS = grouped
     if world > 1:
         t = torch.tensor([dt], device="cpu" if args.rehearse_backend else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,7 +271,8 @@ def main():
                     continue
                 avg_s = p["ms"] / p["count"] * 1e-3
                 out.append(dict(name=name, count=p["count"], total_ms=p["ms"], avg_us=avg_s * 1e6,
-                                gbs=p["bytes"] / p["count"] / avg_s / 1e9, tfs=p["flops"] / p["count"] / avg_s / 1e12))
+                                gbs=p["bytes"] / p["count"] / avg_s / 1e9, tfs=p["flops"] / p["count"] / avg_s / 1e12,
+                                bytes_per_launch=p["bytes"] / p["count"]))
             out.sort(key=lambda r: -r["total_ms"])
             print(f"[bench] {title}:", file=sys.stderr)
             for r in out:
@@ -272,15 +287,18 @@ def main():
         def roof(dom):
             if dom is None:
                 return None
+            per_problem = measured_traffic(dom["name"])
+            problems = (prof_problems or {}).get(dom["name"], {}).get("count", 0) / dom["count"] if dom["count"] else 0.0
+            extra = {"traffic": per_problem * problems if (per_problem and problems) else None,
+                     "traffic_per_problem": per_problem, "problems_per_launch": round(problems, 3),
+                     "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                     "avg_launch_us": dom["avg_us"], "launches": dom["count"],
+                     "measured": "one extra untimed step on a single stream"}
             if dom["name"].startswith("gemm"):
                 return {"kernel": dom["name"], "bound": "mfma", "achieved": dom["tfs"], "peak": MFMA_BF16_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": dom["tfs"] / MFMA_BF16_PEAK_TF, "traffic": measured_traffic(dom["name"]),
-                        "avg_launch_us": dom["avg_us"], "launches": dom["count"],
-                        "measured": "one extra untimed step on a single stream"}
+                        "unit": "TFLOP/s", "frac": dom["tfs"] / MFMA_BF16_PEAK_TF, **extra}
             return {"kernel": dom["name"], "bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": measured_traffic(dom["name"]),
-                    "avg_launch_us": dom["avg_us"], "launches": dom["count"],
-                    "measured": "one extra untimed step on a single stream"}
+                    "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, **extra}
         roofline = roof(own[0] if own else None)
         gemms = [r for r in own if r["name"].startswith("gemm")]
         roofline_gemm = roof(gemms[0] if gemms else None)

@@ -779,13 +779,13 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                      "slim_gemm_nt_bf16: split-K supports C_f32 / C_bf16 outputs, or C_bf16 / C^T_bf16");
         {
             // the product proper (its own scope, so that the scope's time per launch is the kernel's)
-            SLIM_PROF(scope, stream, 2.0 * ((double)g.M + g.N) * g.Kd + 4.0 * g.splits * (double)g.M * g.N,
+            SLIM_PROF(scope, stream, (2.0 * ((double)g.M + g.N) * g.Kd + 4.0 * g.splits * (double)g.M * g.N) * batch,
                       2.0 * g.M * g.N * g.Kd * batch);
             dim3 grid((unsigned)tiles, (unsigned)g.splits, (unsigned)batch);
             hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, g);
             SLIM_LAUNCH_CHECK();
         }
-        SLIM_PROF("splitk_reduce", stream, 4.0 * g.splits * (double)g.M * g.N + out_bytes);
+        SLIM_PROF("splitk_reduce", stream, (4.0 * g.splits * (double)g.M * g.N + out_bytes) * batch);
         if (g.Ct16) {
             dim3 tgrid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)batch);
             SLIM_REQUIRE(tgrid.y <= 65535, "slim_gemm_nt_bf16: too many rows for the transposing reduction");
@@ -801,7 +801,7 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
         SLIM_LAUNCH_CHECK();
         return SLIM_OK;
     }
-    SLIM_PROF(scope, stream, 2.0 * ((double)g.M + g.N) * g.Kd + out_bytes, 2.0 * g.M * g.N * g.Kd * batch);
+    SLIM_PROF(scope, stream, (2.0 * ((double)g.M + g.N) * g.Kd + out_bytes) * batch, 2.0 * g.M * g.N * g.Kd * batch);
     hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, 1, (unsigned)batch), dim3(256), lds_bytes, (hipStream_t)stream, g);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;

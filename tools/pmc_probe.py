@@ -27,9 +27,8 @@ def bf(*shape):
 
 
 def gram_splits(rows):
-    tiles = 25
-    splits = min((512 + tiles - 1) // tiles, (rows + 63) // 64 // 4, 16)
-    return max(splits, 1)
+    # the fit's choice while several fits run side by side (symmetric tiles: both operands are Xt)
+    return max(2, (rows + 63) // 64 // 32)
 
 
 def ns_step(X, Xt):
