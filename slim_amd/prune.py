@@ -42,6 +42,10 @@ SHARED_EIGH = os.environ.get("SLIM_SHARED_EIGH", "1") == "1"
 # as one lockstep chain (SLIM_GROUP_FITS=0: one chain per linear)
 GROUP_FITS = os.environ.get("SLIM_GROUP_FITS", "1") == "1"
 GROUP_MAX = int(os.environ.get("SLIM_GROUP_MAX", "0"))
+# with lockstep groups: prepare all linears (mask, first scale search, error matrix) in a phase of their own instead of
+# at the head of their group's chain (measured slower, 44.6 vs 42.6 ms per block: the phase's barrier costs more than the
+# serial prepares of a chain, so it is off)
+PREPARE_PHASE = os.environ.get("SLIM_PREPARE_PHASE", "0") == "1"
 # which of the side streams carry the chains when there are at most that many: HIP spreads a process's streams over four
 # in-order hardware queues, and these four of the seven side streams sit on four different ones
 GROUP_STREAM_IDS = [int(x) for x in os.environ.get("SLIM_GROUP_STREAMS", "0,1,2,6").split(",") if x != ""]
@@ -376,16 +380,26 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
                 ctxs[idx] = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
                                              separate_lora, tile, quantize_first, scale_important_weights, E_out, Et_out)
 
+            def prepare_member(g, b):
+                idx = fit_groups[g][1][b]
+                if gbuf[g] is None or gbuf[g][2] != 0:
+                    prepare_into(idx, None, None)
+                else:                                   # without deflation the error matrices are the strided operands
+                    prepare_into(idx, gbuf[g][0][b], gbuf[g][1][b])
+                return ctxs[idx].tensors()
+
             def front(g):
                 members = fit_groups[g][1]
                 l, b0 = where[g]
                 if gbuf[g] is None:
-                    prepare_into(members[0], None, None)
+                    if not PREPARE_PHASE:
+                        prepare_member(g, 0)
                     _lora.add_lora_fit_front(ctxs[members[0]], Mb[l][b0], sketch_split=split)
                 else:
                     Eg, Etg, t = gbuf[g]
-                    for b, idx in enumerate(members):       # without deflation the error matrices are the strided operands
-                        prepare_into(idx, Eg[b] if t == 0 else None, Etg[b] if t == 0 else None)
+                    if not PREPARE_PHASE:
+                        for b in range(len(members)):
+                            prepare_member(g, b)
                     _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], Eg, Etg,
                                                    sketch_split=split)
                 return [x for i in members for x in ctxs[i].tensors()] + ([gbuf[g][0], gbuf[g][1]] if gbuf[g] else [])
@@ -413,6 +427,9 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
             # (splitting the linears into two groups so that one group's chain overlaps the other's GEMM-heavy halves was
             # measured slower, 56.7 vs 47 ms: the extra barriers cost more than the idle chip during the shared chain)
             ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
+            if PREPARE_PHASE:       # mask, scale search and error matrix of every linear side by side, off the chains
+                run_on_streams([lambda g=g, b=b: prepare_member(g, b) for g in range(len(fit_groups))
+                                for b in range(len(fit_groups[g][1]))], dev, n_streams)
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
             tails = {l: torch.zeros(n, dtype=torch.int32, device=dev) for l, n in count.items()}
