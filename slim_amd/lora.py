@@ -241,12 +241,12 @@ def fit_error_matrix_back_group(p, d, e, Q, vecs, ss, tail_info=None):
     return out
 
 
-def fit_error_matrix_back(p, d, e, Q, vecs, s):
+def fit_error_matrix_back(p, d, e, Q, vecs, s, tail_info=None):
     """Second half of fit_error_matrix: (d, e, Q) = the tridiagonalised Rayleigh-Ritz matrix of this layer; returns what
     fit_error_matrix returns, from the same arithmetic."""
     N, K, rank, t = p["N"], p["K"], p["rank"], p["t"]
     r8 = _round_up8(rank)
-    fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s)
+    fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s, tail_info=tail_info)
     if t == 0:
         U, Ut, L = fit["U"], fit["Ut"], fit["L"]
         if r8 != rank:
@@ -485,10 +485,10 @@ def add_lora_fit_front(c, M_out, sketch_split=True):
     c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out, sketch_split)
 
 
-def add_lora_fit_back(c, d, e, Q, vecs):
-    """Second phase, second half."""
+def add_lora_fit_back(c, d, e, Q, vecs, tail_info=None):
+    """Second phase, second half (tail_info: see ops.lowrank_fit_back)."""
     c.touch()
-    c.fit = fit_error_matrix_back(c.pending, d, e, Q, vecs, c.s if c.separate else None)
+    c.fit = fit_error_matrix_back(c.pending, d, e, Q, vecs, c.s if c.separate else None, tail_info)
     c.pending = None
 
 

@@ -409,15 +409,15 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
                 l, b0 = where[g]
                 d, e, Q = tri[l]
                 if gbuf[g] is None:
-                    _lora.add_lora_fit_back(ctxs[members[0]], d[b0], e[b0], Q[b0], Mb[l][b0])
+                    _lora.add_lora_fit_back(ctxs[members[0]], d[b0], e[b0], Q[b0], Mb[l][b0], tails[l][b0:b0 + 1])
                 else:
                     sl = slice(b0, b0 + len(members))
                     _lora.add_lora_fit_back_group([ctxs[i] for i in members], d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
                 return [x for i in members for x in ctxs[i].tensors()]
 
             def tail(g, b, tri):
-                # the second stage of a grouped member's eigen-solve (a library call per problem): one job per member, so
-                # that the members' solves overlap instead of queueing on their group's stream
+                # the second stage of a member's eigen-solve (a library call per problem): one job per member, so that the
+                # solves overlap instead of queueing on their group's stream
                 l, b0 = where[g]
                 d, e, Q = tri[l]
                 r_fit = ctxs[fit_groups[g][1][0]].pending["ctx"]["r"]
@@ -433,7 +433,7 @@ def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
             tails = {l: torch.zeros(n, dtype=torch.int32, device=dev) for l, n in count.items()}
-            run_on_streams([lambda g=g, b=b: tail(g, b, tri) for g in range(len(fit_groups)) if gbuf[g] is not None
+            run_on_streams([lambda g=g, b=b: tail(g, b, tri) for g in range(len(fit_groups))
                             for b in range(len(fit_groups[g][1]))], dev, n_streams)
             run_on_streams([lambda g=g: back(g, tri) for g in range(len(fit_groups))], dev, n_streams, ids)
             run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
