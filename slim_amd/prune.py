@@ -27,6 +27,9 @@ CALIBRATION_BATCH = int(os.environ.get("SLIM_CALIBRATION_BATCH", "8"))
 KEEP_ON_DEVICE = False
 # optional callable(i, name, module, wrapped) invoked after each linear is compressed (tests, tracing)
 LAYER_CALLBACK = None
+# optional callable(i, name, wrapped) invoked once the statistics of a block's linear are final (after shift_zeros) and
+# before anything is derived from them; it may replace wrapped.scaler_row (tests inject recorded statistics)
+STATS_CALLBACK = None
 # HIP streams over which the independent linears of one block are compressed concurrently.  The l x l
 # eigen-solve of one linear is a long chain of tiny kernels; on its own stream it overlaps the GEMM-heavy
 # phases of the other linears.  Each stream is fed by its own host thread (run_on_streams); 7 = one per linear
@@ -239,7 +242,28 @@ def _run_block(layer, src, dst, kwargs, batch):
             dst[j:j + batch] = out
 
 
-def compress_linears(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
+def check_fit_status(items):
+    """Raise if the low-rank fit of any of these linears reported a failure (a status word of its eigen-solver or of an
+    orthonormalisation is non-zero): such a fit leaves arbitrary adapters and a residual weight quantised against them.
+    One host synchronisation for the whole block."""
+    named = [(name, lin.lora_fit_info) for name, lin, _ in items if getattr(lin, "lora_fit_info", None) is not None]
+    if not named:
+        return
+    bad = torch.stack([info.ne(0).any() for _, info in named]).cpu().tolist()
+    failed = [(name, info.cpu().tolist()) for (name, info), b in zip(named, bad) if b]
+    if failed:
+        from ._lib import SlimHipError, ERR_SOLVER
+        raise SlimHipError("low-rank fit", ERR_SOLVER, "; ".join(
+            f"{name}: status words {[w for w in words if w][:8]}" for name, words in failed))
+
+
+def compress_linears(items, dev, *args, **kwargs):
+    """compress_linears_unchecked + check_fit_status (the driver's entry)."""
+    compress_linears_unchecked(items, dev, *args, **kwargs)
+    check_fit_status(items)
+
+
+def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
                      quantize_lora=False, pad_lora=False, lora_tile_size=256, separate_lora=True, quantize_first=True,
                      scale_important_weights=False, tiled_weight_quantization=False, callback=None, describe=None,
                      n_streams=None):
@@ -540,6 +564,9 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         if shift_zero_metrics:
             for name in subset:
                 wrapped_layers[name].scaler_row = ops.shift_zeros(wrapped_layers[name].scaler_row)
+        if STATS_CALLBACK is not None:
+            for name in subset:
+                STATS_CALLBACK(i, name, wrapped_layers[name])
         block_stats(list(wrapped_layers.values()))
 
         names = list(subset)

@@ -1,6 +1,7 @@
 """Packed 2:4 int4 storage and the fused forward pass, against the reference's emulated forward
 (nn.Linear on the dequantised bf16 weight + add_lora_hook, slim/prune.py:303-321) run with torch on the
 same GPU, and against an fp64 evaluation of the same expression."""
+import functools
 import math
 
 import pytest
@@ -20,10 +21,11 @@ def ops():
     return _ops
 
 
+@functools.lru_cache(maxsize=2)
 def make_weight(N, K, seed, sf=None):
     """A weight of the form the compression leaves behind: 2:4 sparse, values bf16(c / sf), c in [-8, 7]."""
     g = torch.Generator().manual_seed(seed)
-    codes = torch.randint(-8, 8, (N, K), generator=g).float()
+    codes = torch.randint(-8, 8, (N, K), generator=g, dtype=torch.int8).float()
     keep = O.prune_nm(torch.rand(N, K, generator=g), 2, 4)        # True = pruned
     sf = torch.tensor(sf if sf is not None else 37.3, dtype=torch.float32)
     W = (codes / sf).to(torch.bfloat16)
@@ -114,6 +116,9 @@ CASES = [
     (256, 512, 128, False, 128, [1, 16, 64, 200]),
     (1024, 4096, 409, False, None, [1, 16, 48, 1000]),
     (4096, 1024, 256, True, 128, [2, 128, 513]),
+    # the forward microbenchmark's layer (LLaMA-3-70B up/gate projection, 10 % rank adapters), quantised and bf16 adapters
+    (28672, 8192, 1024, False, 256, [1, 16, 256, 1024]),
+    (28672, 8192, 1024, False, None, [1, 16, 256, 1024]),
 ]
 
 

@@ -176,12 +176,23 @@ def test_scale_search_golden(ops, golden, tag):
     if len(fine_idx):
         torch.testing.assert_close(tl[fine_idx], fine_loss, rtol=1e-5, atol=0)
     ref_sf = float(g[tag + "_sf"])
-    ref_idx = int(torch.argmin(torch.where(torch.isfinite(tl), tl, torch.tensor(float("inf"))))) if len(fine_idx) else 0
-    assert int(idx) == ref_idx
-    # the reference's own argmin may sit on a neighbouring bin when two fp32 losses tie to rounding
+    # the chosen bin against the REFERENCE's own losses (the fixture's fine scan): the first minimum, as torch.min
+    # returns it (quantization.py:57-61).  Where the reference's runner-up is within 1e-5 relative of its minimum
+    # (its fp32 sums and the kernel's fp64 sums may then order the two differently) any of the tied bins passes.
+    if len(fine_idx):
+        best = int(torch.argmin(fine_loss))
+        ref_idx = int(fine_idx[best])
+        tied = {int(i) for i, l in zip(fine_idx.tolist(), fine_loss.tolist()) if l <= float(fine_loss[best]) * (1 + 1e-5)}
+        assert int(idx) in tied, (int(idx), ref_idx, sorted(tied))
+        if len(tied) == 1:
+            assert int(idx) == ref_idx
+    else:
+        ref_idx = 0                     # empty fine scan: the reference returns val[0] (quantization.py:50-62)
+        assert int(idx) == 0
+    # the reference's scale is 7 / val[its bin]
     ref_alpha = 7.0 / ref_sf
-    assert abs(float(alpha) - ref_alpha) <= 2.5 * float(val[1] - val[0]) + 1e-6 * ref_alpha
-    if int(idx) == int(torch.argmin((g[tag + "_val"] - ref_alpha).abs())):
+    assert abs(float(g[tag + "_val"][ref_idx]) - ref_alpha) <= 1e-6 * ref_alpha
+    if int(idx) == ref_idx:
         assert float(sf) == ref_sf      # same bin -> bit-identical scaling factor
 
 

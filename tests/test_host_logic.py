@@ -94,3 +94,62 @@ def test_wrapper_state_and_cpu_refusal():
     assert w.rows == 8 and w.columns == 16 and w.nsamples == 0 and w.scaler_row.shape == (16,)
     with pytest.raises(RuntimeError, match="no CPU path"):
         w.add_batch(torch.zeros(1, 4, 16, dtype=torch.bfloat16), None)
+
+
+def _g8_model(tag):
+    from transformers import OPTConfig, OPTForCausalLM, LlamaConfig, LlamaForCausalLM
+    if tag == "opt":
+        m = OPTForCausalLM(OPTConfig(vocab_size=256, hidden_size=256, ffn_dim=512, num_hidden_layers=2,
+                                     num_attention_heads=4, max_position_embeddings=32, word_embed_proj_dim=256))
+    else:
+        m = LlamaForCausalLM(LlamaConfig(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                                         num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=32))
+    m = m.to(torch.bfloat16).eval()
+    m.config.max_position_embeddings = 32
+    return m
+
+
+@pytest.mark.parametrize("tag", ["opt", "llama"])
+def test_eval_ppl_matches_reference_outputs(golden, tag):
+    """eval_ppl_wikitext against the numbers the reference's own harness (slim/eval.py:52-116) printed for the same
+    models on the same token stream: the dense model, and the model carrying the reference's compressed tensors with
+    the adapter hook (slim/prune.py:303-321).  Both sides run the torch CPU forward, so the bf16-loss perplexity must
+    agree to fp32 rounding of the final exp; the fp32-loss figure of the fixture was accumulated sample by sample
+    (batch 1), ours in batches of 2: 1e-5 relative."""
+    from slim_amd.eval import eval_ppl_wikitext
+    from slim_amd.prune import add_lora_hook
+    from slim_amd.utils import get_layers_list, find_layers
+    g = golden("g8_e2e_" + tag)
+    model = _g8_model(tag)
+    model.load_state_dict({k: g["init/" + k] for k in g["state_keys"].tolist()})
+
+    class Enc:
+        input_ids = g["eval_ids"]
+    assert eval_ppl_wikitext(model, Enc, 2, "cpu") == pytest.approx(float(g["ppl_dense"]), rel=1e-6)
+    assert eval_ppl_wikitext(model, Enc, 2, "cpu", fp32_loss=True) == pytest.approx(float(g["ppl_dense_fp32loss"]), rel=1e-5)
+    for i, layer in enumerate(get_layers_list(model)):
+        for name, lin in find_layers(layer).items():
+            p = f"L{i}/{name}/"
+            lin.weight.data = g[p + "weight"]
+            lin.lora_left = torch.nn.Parameter(g[p + "lora_left"])
+            lin.lora_right = torch.nn.Parameter(g[p + "lora_right"])
+            lin.lora_rank = torch.tensor(int(g[p + "lora_rank"]))
+            lin.register_forward_hook(add_lora_hook)
+    assert eval_ppl_wikitext(model, Enc, 2, "cpu") == pytest.approx(float(g["ppl_slim"]), rel=1e-6)
+    assert eval_ppl_wikitext(model, Enc, 2, "cpu", fp32_loss=True) == pytest.approx(float(g["ppl_slim_fp32loss"]), rel=1e-5)
+
+
+def test_failed_fit_status_is_raised():
+    """A non-zero status word of a linear's low-rank fit stops the driver instead of installing the adapters silently."""
+    from slim_amd.prune import check_fit_status
+    from slim_amd._lib import SlimHipError
+
+    class Lin:
+        pass
+    ok, bad = Lin(), Lin()
+    ok.lora_fit_info = torch.zeros(64, dtype=torch.int32)
+    bad.lora_fit_info = torch.zeros(64, dtype=torch.int32)
+    bad.lora_fit_info[5] = 3
+    check_fit_status([("q_proj", ok, None), ("no_fit", Lin(), None)])
+    with pytest.raises(SlimHipError, match="k_proj"):
+        check_fit_status([("q_proj", ok, None), ("k_proj", bad, None)])

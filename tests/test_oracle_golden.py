@@ -121,3 +121,31 @@ def test_g9_input_quant(golden):
         assert torch.equal(O.quantize_input_fp8(x.clone()), g[f"{tag}_b8_g-1"])
         assert torch.equal(O.quantize_input_int(x.clone(), 4, 64), g[f"{tag}_b4_g64"])
         assert torch.equal(O.quantize_input_int(x.clone(), 6, -1), g[f"{tag}_b6_g-1"])
+
+
+@pytest.mark.parametrize("tag", ["opt", "llama"])
+def test_g13_oracle_reproduces_reference_end_to_end_layers(golden, tag):
+    """Every linear of the reference's end-to-end runs (g8), from the statistics the reference's add_lora received
+    (g13): mask, first-pass codes and scale, final weight, adapters and second scale, all bit for bit."""
+    import math
+    g8, g13 = golden("g8_e2e_" + tag), golden("g13_e2e_stats_" + tag)
+    prefix = "model.decoder.layers" if tag == "opt" else "model.layers"
+    for i in range(2):
+        for name in g13["names"].tolist():
+            p = f"L{i}/{name}/"
+            W = g8[f"init/{prefix}.{i}.{name}.weight"]
+            sr = g13[p + "scaler_row"]
+            mask_ref = torch.from_numpy(np.unpackbits(g13[p + "mask"].numpy(), axis=1)[:, :W.shape[1]]).bool()
+            sal = torch.abs(W) * g13[p + "s"].reshape(1, -1)
+            assert torch.equal(O.prune_nm(sal, 2, 4), mask_ref), p
+            codes, sf = O.quantize_per_tensor(W, 4)
+            assert torch.equal(codes, g13[p + "codes1"]) and torch.equal(sf.reshape(-1), g13[p + "sf1"].reshape(-1)), p
+            out = O.add_lora(W, mask_ref, sr, 0.1, num_bits=4, tile=128)
+            r = int(g8[p + "lora_rank"])
+            assert out["rank"] == r
+            assert torch.equal(out["weight"], g8[p + "weight"]), p
+            assert torch.equal(out["scaling_factor"].reshape(-1), g8[p + "sf"].reshape(-1)), p
+            # the driver multiplies the adapters by sqrt(rank) (slim/prune.py:324-326)
+            sq = torch.sqrt(torch.tensor(r))
+            assert torch.equal(out["lora_left"] * sq, g8[p + "lora_left"]), p
+            assert torch.equal(out["lora_right"] * sq, g8[p + "lora_right"]), p
