@@ -113,6 +113,15 @@ int slim_hist_abs_bf16(const void* W_bf16, int64_t numel, uint32_t* hist, int ac
 int64_t slim_quant_search_workspace_bytes(int num_bins);
 int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out, int32_t* idx_out,
                       float* sf_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* slim_quant_search for callers that cannot allocate or bring a workspace (HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is a 240 128-byte array inside the
+ * library's code object (one copy per GPU, held until the process ends), enough for num_bins <= 20000; more bins return
+ * SLIM_ERR_INVALID.  Calls no hipMalloc / hipFree.  The first call on a device resolves that device's copy of the array
+ * (hipGetSymbolAddress) and sets a kernel attribute: make it outside a capture.  All calls on one GPU share the array:
+ * calls that overlap on one GPU (different streams or threads) race; calls on one stream are ordered.  Results are
+ * identical to slim_quant_search. */
+int slim_quant_search_noalloc(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out, int32_t* idx_out,
+                              float* sf_out, void* stream);
 /* abs-max scale (slim_quant = False, quantization.py:190-194): alpha = max|w| (bf16 value),
  * sf = bf16(bf16(1 / alpha) * maxq) widened to fp32. */
 int slim_absmax_scale(const uint32_t* hist, int num_bits, float* alpha_out, float* sf_out, void* stream);

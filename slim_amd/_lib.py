@@ -34,6 +34,7 @@ PROTOTYPES = {
     "slim_hist_abs_bf16": (i32, [vp, i64, vp, i32, vp]),
     "slim_quant_search_workspace_bytes": (i64, [i32]),
     "slim_quant_search": (i32, [vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "slim_quant_search_noalloc": (i32, [vp, i32, i32, vp, vp, vp, vp]),
     "slim_absmax_scale": (i32, [vp, i32, vp, vp, vp]),
     "slim_quantize_pt": (i32, [vp, i64, vp, i32, vp, vp]),
     "slim_dequantize_pt": (i32, [vp, i64, vp, vp, i32, vp]),

@@ -12,6 +12,7 @@
 // last bin closed, and the same density normalisation (count/total)/width.
 #include "common.hpp"
 #include "../../include/slim_hip.h"
+#include <mutex>
 
 #define HIST_BINS 32768
 #define MAX_SEARCH_BINS 20000
@@ -275,17 +276,10 @@ __global__ __launch_bounds__(1024) void search_argmin_kernel(const float* ws_bas
     }
 }
 
-extern "C" int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out,
-                                 int32_t* idx_out, float* sf_out, void* workspace, int64_t workspace_bytes,
-                                 void* stream) {
-    SLIM_REQUIRE(hist && alpha_out && workspace, "slim_quant_search: null pointer");
-    SLIM_REQUIRE(num_bins >= 10 && num_bins <= MAX_SEARCH_BINS, "slim_quant_search: num_bins must be in [10, 20000]");
-    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 16, "slim_quant_search: num_bits out of range");
-    SLIM_REQUIRE(workspace_bytes >= slim_quant_search_workspace_bytes(num_bins), "slim_quant_search: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
+// the four launches of the search on a workspace of slim_quant_search_workspace_bytes(num_bins) bytes
+static int launch_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out, int32_t* idx_out,
+                         float* sf_out, float* ws, hipStream_t st) {
     SLIM_HIP(slim_allow_dynamic_lds((const void*)rebin_kernel, MAX_SEARCH_BINS * 4));
-    SLIM_PROF("quant_search", stream);
-    float* ws = (float*)workspace;
     rebin_kernel<<<1, 1024, (size_t)num_bins * 4, st>>>(hist, num_bins, ws);
     SLIM_LAUNCH_CHECK();
     const int stride = num_bins / 10;
@@ -297,6 +291,55 @@ extern "C" int slim_quant_search(const uint32_t* hist, int num_bins, int num_bit
     search_argmin_kernel<<<1, 1024, 0, st>>>(ws, num_bins, num_bits, alpha_out, idx_out, sf_out);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
+}
+
+extern "C" int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out,
+                                 int32_t* idx_out, float* sf_out, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    SLIM_REQUIRE(hist && alpha_out && workspace, "slim_quant_search: null pointer");
+    SLIM_REQUIRE(num_bins >= 10 && num_bins <= MAX_SEARCH_BINS, "slim_quant_search: num_bins must be in [10, 20000]");
+    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 16, "slim_quant_search: num_bits out of range");
+    SLIM_REQUIRE(workspace_bytes >= slim_quant_search_workspace_bytes(num_bins), "slim_quant_search: workspace too small");
+    SLIM_PROF("quant_search", stream);
+    return launch_search(hist, num_bins, num_bits, alpha_out, idx_out, sf_out, (float*)workspace, (hipStream_t)stream);
+}
+
+// ---- the search without a caller workspace and without any allocation ------------------------------------
+// Search workspace for the largest histogram the search supports (3 * 20000 + 32 floats = 240 128 bytes), as a
+// device array of this library's code object: every GPU the library runs on holds its own copy, at its own address,
+// until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress; the device
+// address it returns (per device) is what the kernels get.
+#define STATIC_SEARCH_FLOATS (3 * MAX_SEARCH_BINS + 32)
+#define SLIM_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[STATIC_SEARCH_FLOATS];
+static float* g_scratch_ptr[SLIM_MAX_DEVICES];  // NULL = not resolved on that device yet
+static std::mutex g_scratch_mu;
+
+extern "C" int slim_quant_search_noalloc(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out,
+                                         int32_t* idx_out, float* sf_out, void* stream) {
+    SLIM_REQUIRE(hist && alpha_out, "slim_quant_search_noalloc: null pointer");
+    SLIM_REQUIRE(num_bins <= MAX_SEARCH_BINS,
+                 "slim_quant_search_noalloc: num_bins %d exceeds the %d bins the library's static scratch holds", num_bins,
+                 MAX_SEARCH_BINS);
+    SLIM_REQUIRE(num_bins >= 10, "slim_quant_search_noalloc: num_bins must be at least 10");
+    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 16, "slim_quant_search_noalloc: num_bits out of range");
+    int dev = -1;
+    SLIM_HIP(hipGetDevice(&dev));
+    SLIM_REQUIRE(dev >= 0 && dev < SLIM_MAX_DEVICES, "slim_quant_search_noalloc: device index %d not supported", dev);
+    float* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {  // first call on this device: resolve this device's copy of the array
+            void* p = nullptr;
+            SLIM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            SLIM_REQUIRE(p != nullptr, "slim_quant_search_noalloc: the scratch array has no address on device %d", dev);
+            g_scratch_ptr[dev] = (float*)p;
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    // rebin_kernel rewrites every word the later kernels read (pdf, val, total_loss below num_bins and the 32 coarse
+    // slots), so what an earlier, larger search left above num_bins is never looked at
+    return launch_search(hist, num_bins, num_bits, alpha_out, idx_out, sf_out, ws, (hipStream_t)stream);
 }
 
 // abs-max of a bf16 tensor from its pattern histogram (the non-SLiM-Quant scale, quantization.py:190):
