@@ -25,7 +25,6 @@ extern "C" {
 #define SLIM_HIP_ABI_VERSION 1
 #define SLIM_FIT_INFO_WORDS 64
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
-#define SLIM_FIT_ONE_SIDED 2   /* re-orthonormalise only the row-side iterate (once per full iteration) */
 #define SLIM_FIT_EXACT_FINAL 8  /* last basis finished by Cholesky-QR (rocSOLVER) instead of the fp32 inverse-square-root polish */
 #define SLIM_FIT_NO_SKETCH_SPLIT 16 /* the caller runs several fits side by side: do not cut the sketch products along the
                                      * reduction (by default the ones that under-fill the chip are) and cut the Gram products
@@ -227,8 +226,9 @@ int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t rows, int l,
  *   E [N, K], Et [K, N] bf16;  outputs U [N, r], Ut [r, N] (= lora_right, may be NULL),
  *   L [K, r] (= lora_left), S fp32 [r] (may be NULL), info_out int32 [SLIM_FIT_INFO_WORDS]
  *   (rocSOLVER status words, all zero on success; may be NULL).
- *   flags: SLIM_FIT_CHOLESKY_QR; ns_steps: quintic Newton-Schulz steps per orthonormalisation (each
- *   lifts a singular value by up to 3.44x, so ns_steps >= log(condition number) / log(3.44); 0 = 4). */
+ *   flags: SLIM_FIT_*; ns_steps: log2 of the conditioning (largest / smallest singular value of an iterate inside the
+ *   subspace) the Newton-Schulz orthonormalisations are sized for, 1 .. 12 (0 = 9): it selects the coefficient schedule
+ *   and the number of steps. */
 int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l);
 int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter, uint32_t seed,
                      int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,

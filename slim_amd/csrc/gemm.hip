@@ -248,6 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
                 // G is fetched before the first store (see above), the arithmetic is the stand-alone polynomial kernel's
                 const float sc = g.poly_scal ? *g.poly_scal : 1.f;
                 const float c2 = sc * sc;
+                const float c4 = g.poly_prescaled ? 1.f : c2 * c2;
                 const bool vg = nc >= 4 && (g.N & 3) == 0 && ((uintptr_t)g.poly_G & 15) == 0;
                 const bool v16 = nc >= 4 && (g.ldc16 & 3) == 0 && ((uintptr_t)g.C16 & 7) == 0;
                 float gv[ITERS][4];
@@ -256,7 +257,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
                     const int row = row0 + rt + it * RSTEP;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) gv[it][u] = 0.f;
-                    if (row >= g.M) continue;
+                    if (row >= g.M || g.poly_b == 0.f) continue;
                     const float* p = g.poly_G + (int64_t)row * g.N + col;
                     if (vg) {
                         const f32x4 t4 = *(const f32x4*)p;
@@ -275,7 +276,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
                     bf16_t o[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        float v = g.poly_b * c2 * gv[it][u] + g.poly_q * c2 * c2 * T[r * TS + c + u];
+                        float v = g.poly_b * c2 * gv[it][u] + g.poly_q * c4 * T[r * TS + c + u];
                         if (row == col + u) v += g.poly_a;
                         o[u] = f32_to_bf16(sc * v);
                     }
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
 // C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n, int N, float alpha, float beta,
                                      float* __restrict__ C32, int64_t ldc32, bf16_t* __restrict__ C16, int64_t ldc16,
-                                     int64_t sSlab, int64_t sC32, int64_t sC16, int sym_tile) {
+                                     int64_t sSlab, int64_t sC32, int64_t sC16, int sym_tile, float c16_diag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t bz = blockIdx.y;          // strided batch
@@ -609,7 +610,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
         if (beta != 0.f) v += beta * C32[row * ldc32 + col];
         C32[row * ldc32 + col] = v;
     }
-    if (C16) C16[row * ldc16 + col] = f32_to_bf16(v);
+    if (C16) C16[row * ldc16 + col] = f32_to_bf16(row == col ? v - c16_diag : v);
 }
 
 // The same reduction for products that also want the transposed bf16 output (the sketch products of the fit): a
@@ -797,7 +798,7 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
         const int64_t n = (int64_t)g.M * g.N;
         dim3 rgrid((unsigned)ceil_div64(n, 256), (unsigned)batch);
         splitk_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32,
-                                                                     g.C16, g.ldc16, g.sSlab, g.sC32, g.sC16, g.sym ? BM : 0);
+                                                                     g.C16, g.ldc16, g.sSlab, g.sC32, g.sC16, g.sym ? BM : 0, g.c16_diag);
         SLIM_LAUNCH_CHECK();
         return SLIM_OK;
     }

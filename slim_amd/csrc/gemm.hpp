@@ -38,6 +38,9 @@ struct GemmArgs {
     const float* poly_G = nullptr;
     const float* poly_scal = nullptr;
     float poly_a = 0.f, poly_b = 0.f, poly_q = 0.f;
+    int poly_prescaled = 0;   // the operands already carry the scaling c^2 (acc is used as it is): C16 = bf16(c (a I + q acc))
+    // split-K only: the bf16 output is C - c16_diag I (the shifted Gram matrix of a Newton-Schulz step); C32 is unshifted
+    float c16_diag = 0.f;
     int64_t poly_sG = 0, poly_sScal = 0;      // batch strides of poly_G / poly_scal
     // tuning aid (slim_gemm_set_trace): when set, workgroup w < trace_cap stores 100 MHz timestamps at
     // trace[8 w ..]: kernel entry, first tile staged, K-loop done, epilogue done

@@ -206,6 +206,50 @@ __global__ void ns_poly_kernel(const float* __restrict__ G, const float* __restr
     P[o] = f32_to_bf16(c * v);
 }
 
+// A = bf16(c^2 G - shift I), c = scal[0] or 1 when scal == NULL: the operand of a Newton-Schulz step's square
+__global__ void shifted_gram_bf16_kernel(const float* __restrict__ G, const float* __restrict__ scal, float shift, int l,
+                                         bf16_t* __restrict__ A) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= l) return;
+    const float c = scal ? scal[blockIdx.z * SCAL_STRIDE] : 1.f;
+    const int64_t o = (int64_t)blockIdx.z * l * l + (int64_t)i * l + j;
+    const float v = c * c * G[o];
+    A[o] = f32_to_bf16(i == j ? v - shift : v);
+}
+
+// ---- Newton-Schulz coefficient schedules ---------------------------------------------------------------------------
+// A step maps every singular value x of the iterate to a x + b x^3 + c x^5.  For singular values known to lie in
+// [2^-e, 1] the odd quintic minimising max |1 - p(x)| on the interval is optimal for the step, and its image interval is
+// the next step's domain; composing these greedy steps shrinks the conditioning about fourfold per step at first and
+// quadratically at the end (a fixed polynomial gains 3.44x per step and stalls at [0.68, 1.13]).  Row e of the table
+// (tools/ns_schedule.py: linear programme on a grid, each interval widened by 5 % at the top for the rounding of bf16
+// iterates and polynomials, positivity checked on [0, 1.05]): `enough` steps leave a conditioning of at most 2.35 -- all an intermediate
+// basis of the subspace iteration needs -- and all `total` steps leave the singular values within 0.5 % of 1.
+#define NS_SCHED_MAX_E 12
+#define NS_SCHED_MAX_STEPS 7
+struct NsStep {
+    float a, b, c;
+};
+struct NsSchedule {
+    int enough, total;
+    NsStep step[NS_SCHED_MAX_STEPS];
+};
+static const NsSchedule kNsSchedule[NS_SCHED_MAX_E + 1] = {
+    {0, 0, {}},
+    {1, 2, {{2.608928f, -3.018470f, 1.397845f}, {1.830920f, -1.161389f, 0.330565f}}},   // 2^-1: all steps -> [0.9999, 1.0001]
+    {1, 2, {{3.715880f, -6.445240f, 3.704211f}, {1.860599f, -1.186662f, 0.328539f}}},   // 2^-2: all steps -> [0.9955, 1.0045]
+    {1, 3, {{5.018020f, -10.880343f, 6.832525f}, {2.012485f, -1.322178f, 0.334595f}, {1.832439f, -1.162303f, 0.330073f}}},   // 2^-3: all steps -> [0.9998, 1.0002]
+    {2, 3, {{6.187269f, -14.988916f, 9.772026f}, {2.358624f, -1.601237f, 0.355535f}, {1.866572f, -1.192093f, 0.328569f}}},   // 2^-4: all steps -> [0.9944, 1.0056]
+    {2, 4, {{7.019487f, -17.945850f, 11.898074f}, {2.835361f, -1.945254f, 0.385560f}, {2.018725f, -1.327552f, 0.334937f}, {1.832662f, -1.162457f, 0.330019f}}},   // 2^-5: all steps -> [0.9998, 1.0002]
+    {3, 4, {{7.525912f, -19.753300f, 13.200213f}, {3.287672f, -2.247777f, 0.413545f}, {2.359361f, -1.601798f, 0.355582f}, {1.866700f, -1.192210f, 0.328570f}}},   // 2^-6: all steps -> [0.9943, 1.0057]
+    {3, 5, {{7.806895f, -20.758127f, 13.924754f}, {3.617011f, -2.458654f, 0.433512f}, {2.830861f, -1.942149f, 0.385278f}, {2.016502f, -1.325638f, 0.334815f}, {1.832581f, -1.162401f, 0.330038f}}},   // 2^-7: all steps -> [0.9998, 1.0002]
+    {4, 5, {{7.955126f, -21.288716f, 14.307496f}, {3.819579f, -2.585373f, 0.445627f}, {3.281919f, -2.244032f, 0.413194f}, {2.353202f, -1.597107f, 0.355194f}, {1.865636f, -1.191241f, 0.328561f}}},   // 2^-8: all steps -> [0.9946, 1.0054]
+    {4, 6, {{8.031288f, -21.561458f, 14.504279f}, {3.932568f, -2.655211f, 0.452333f}, {3.612559f, -2.455845f, 0.433245f}, {2.822601f, -1.936443f, 0.384761f}, {2.012468f, -1.322163f, 0.334594f}, {1.832438f, -1.162303f, 0.330073f}}},   // 2^-9: all steps -> [0.9998, 1.0002]
+    {5, 6, {{8.069896f, -21.699746f, 14.604063f}, {3.992338f, -2.691930f, 0.455866f}, {3.816823f, -2.583663f, 0.445464f}, {3.274655f, -2.239300f, 0.412749f}, {2.345510f, -1.591237f, 0.354711f}, {1.864334f, -1.190056f, 0.328552f}}},   // 2^-10: all steps -> [0.9948, 1.0052]
+    {5, 7, {{8.089333f, -21.769373f, 14.654306f}, {4.023083f, -2.710758f, 0.457679f}, {3.931025f, -2.654260f, 0.452241f}, {3.607575f, -2.452699f, 0.432945f}, {2.813427f, -1.930097f, 0.384187f}, {2.008060f, -1.318357f, 0.334355f}, {1.832287f, -1.162201f, 0.330111f}}},   // 2^-11: all steps -> [0.9998, 1.0002]
+    {6, 7, {{8.099085f, -21.804308f, 14.679517f}, {4.038681f, -2.720296f, 0.458598f}, {3.991523f, -2.691430f, 0.455818f}, {3.813886f, -2.581841f, 0.445289f}, {3.266954f, -2.234280f, 0.412278f}, {2.337455f, -1.585078f, 0.354205f}, {1.863001f, -1.188844f, 0.328545f}}},   // 2^-12: all steps -> [0.9951, 1.0049]
+};
+
 // ---- workspace ----------------------------------------------------------------------------------
 #define GRAM_MAX_SPLITS 16
 #define SKETCH_MAX_SPLITS 3
@@ -325,7 +369,10 @@ static int nt(int batch, const bf16_t* A, int64_t lda, int64_t sA, const bf16_t*
 // G (fp32) and optionally G16 (bf16) <- Xt Xt^T per problem, reduction over `rows` split so that tiles * splits
 // covers the chip.  The split count depends on the shape only (not on the batch size), so a batched fit adds its
 // partial sums in the same order as a single one.
-static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, void* stream) {
+// diag16 != 0: G16 receives bf16(G - diag16 I); *shifted tells whether that happened (it needs the split-K reduction, which
+// short reductions do not have -- the caller then forms the shifted copy itself)
+static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, void* stream, float diag16 = 0.f,
+                bool* shifted = nullptr) {
     const int tiles = ((l + 127) / 128) * ((l + 127) / 128);
     int splits = (512 + tiles - 1) / tiles;
     const int nk = (int)((rows + 63) / 64);
@@ -354,6 +401,15 @@ static int gram(const bf16_t* Xt, int64_t rows, int l, FitWs& w, bf16_t* G16, vo
     g.sSlab = (int64_t)GRAM_MAX_SPLITS * l * l;
     g.sym = 1;          // honoured when the product is cut along the reduction (the reduction mirrors the lower tiles)
     gemm_plan_splits(g, splits);
+    if (shifted) *shifted = false;
+    if (diag16 != 0.f) {
+        if (g.splits > 1) {
+            g.c16_diag = diag16;
+            if (shifted) *shifted = true;
+        } else {
+            g.C16 = nullptr;
+        }
+    }
     return slim_gemm_launch(g, stream);
 }
 
@@ -405,83 +461,44 @@ static int cholesky_qr(const Pair& src, const Pair& dst, int64_t rows, int l, Fi
     return nt(w.batch, src.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, dst.X, l, dst.Xt, rows, stream);
 }
 
-// dst <- X G^(-1/2), G = X^T X: the polish of a basis that Newton-Schulz has already brought close to orthonormal
-// (eigenvalues of G within [0.46, 1.28]).  G^(-1/2) comes from the coupled Newton-Schulz iteration
-//     T = (3 I - Z Y) / 2,  Y <- Y T,  Z <- T Z,   Y0 = G, Z0 = I   (Y -> G^(1/2), Z -> G^(-1/2), error squared per step)
-// on the l x l matrices in fp32 (library GEMMs: three per step, a dozen microseconds each; eight steps take an
-// eigenvalue of 0.01 to 0.997), which replaces the
-// Cholesky factorisation and triangular inversion of cholesky_qr (forty-odd solver launches, 1.6 ms at l = 640,
-// most of it in single-workgroup diagonal-block kernels).  A direction the iterate has lost entirely (eigenvalue
-// of G near zero) is not restored by this -- its column stays near zero and drops to the bottom of the
-// Rayleigh-Ritz spectrum; cholesky_qr remains the choice where the basis must span the whole space.
-__global__ void scaled_identity_kernel(float* __restrict__ a, int l, float value) {
-    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < l) a[(int64_t)blockIdx.z * l * l + (int64_t)i * l + j] = i == j ? value : 0.f;
-}
-
-#define POLISH_STEPS 8
-static int invsqrt_qr(const Pair& src, const Pair& dst, int64_t rows, int l, FitWs& w, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    rb_handle h = nullptr;
-    CHK(solver_handle(st, &h));
-    SLIM_REQUIRE(g_solver.sgemm, "slim_lowrank_fit: rocblas_sgemm not available");
-    CHK(gram(src.Xt, rows, l, w, nullptr, stream));
-    const int64_t sG = (int64_t)l * l;
-    const dim3 grid((unsigned)((l + 255) / 256), (unsigned)l, (unsigned)w.batch);
-    const float one = 1.f, zero = 0.f, mhalf = -0.5f, threehalves = 1.5f;
-    int tok = g_slim_prof_on ? slim_prof_begin("polish_invsqrt", st, 0.0, 6.0 * POLISH_STEPS * l * (double)l * l * w.batch) : -1;
-    // the split-K slab is free between Gram products: Z, its successor and T live there
-    float* Y = w.G;
-    float* Y2 = w.G2;
-    float* Z = w.slab;
-    float* Z2 = w.slab + sG * w.batch;
-    float* T = w.slab + 2 * sG * w.batch;
-    scaled_identity_kernel<<<grid, 256, 0, st>>>(Z, l, 1.f);
-    SLIM_LAUNCH_CHECK();
-    for (int it = 0; it < POLISH_STEPS; ++it) {
-        scaled_identity_kernel<<<grid, 256, 0, st>>>(T, l, 1.f);
-        SLIM_LAUNCH_CHECK();
-        for (int b = 0; b < w.batch; ++b) {
-            float *y = Y + b * sG, *y2 = Y2 + b * sG, *z = Z + b * sG, *z2 = Z2 + b * sG, *t = T + b * sG;
-            // every matrix here is a polynomial in G: symmetric, so row- and column-major views coincide
-            if (g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, l, l, l, &mhalf, z, l, y, l, &threehalves, t, l) != 0 ||
-                g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, l, l, l, &one, y, l, t, l, &zero, y2, l) != 0 ||
-                g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, l, l, l, &one, t, l, z, l, &zero, z2, l) != 0) {
-                slim_set_error("rocblas_sgemm failed");
-                return SLIM_ERR_SOLVER;
-            }
-        }
-        float* tmp = Y; Y = Y2; Y2 = tmp;
-        tmp = Z; Z = Z2; Z2 = tmp;
-    }
-    if (tok >= 0) slim_prof_end(tok, st);
-    ns_poly_kernel<<<grid, 256, 0, st>>>(Z, nullptr, nullptr, 0.f, 1.f, 0.f, l, w.T16);      // bf16(Z)
-    SLIM_LAUNCH_CHECK();
-    return nt(w.batch, src.X, l, rows * l, w.T16, l, sG, (int)rows, l, l, nullptr, dst.X, l, dst.Xt, rows, stream);
-}
-
-// Newton-Schulz orthonormalisation on MFMA: X <- X p(X^T X) keeps the column space and drives every
-// singular value towards 1.  `nq` quintic steps (3.4445, -4.7750, 2.0315: fast, settles in [0.68, 1.13]),
-// then `nc` cubic steps (1.5, -0.5: converges to 1 quadratically).  Each step is the l x l Gram matrix
-// (one tall GEMM), its square (one small GEMM), the polynomial (element-wise) and X P (one tall GEMM).
-// bufs[cur] holds the input; returns the index of the buffer holding the result.
-static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, FitWs& w, void* stream, int* out_idx) {
+// Newton-Schulz orthonormalisation on MFMA: X <- X (a I + b G + c G^2), G = X^T X, keeps the column space and drives
+// every singular value towards 1 (coefficients per step: a schedule of kNsSchedule, or fixed ones).  The first step
+// works on X / sqrt(||G||_F), whose singular values are at most 1.  Each step is the l x l Gram matrix (one tall GEMM),
+// for c != 0 its square with the polynomial evaluated in the product's epilogue (one small GEMM; c == 0: an element-wise
+// kernel) and X P (one tall GEMM).  bufs[cur] holds the input; returns the index of the buffer holding the result.
+static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, const NsStep* steps, int nsteps, FitWs& w, void* stream,
+                   int* out_idx) {
     hipStream_t st = (hipStream_t)stream;
     const dim3 pgrid((unsigned)((l + 255) / 256), (unsigned)l, (unsigned)w.batch);
     const int64_t sG = (int64_t)l * l;
-    for (int sidx = 0; sidx < nq + nc; ++sidx) {
-        const bool quintic = sidx < nq;
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+        const NsStep& c = steps[sidx];
         const Pair& x = bufs[cur];
         const int nxt = (cur + 1) % 3;
-        CHK(gram(x.Xt, rows, l, w, w.G16, stream));
+        // a + b x + c x^2 = c (x - alpha)^2 + gamma, alpha = -b / (2 c), gamma = a - b^2 / (4 c): the square of the SHIFTED
+        // Gram matrix.  Its bf16 rounding error enters the polynomial multiplied by 2 c |x - alpha| (about 1 % for the
+        // steepest first steps), where the expanded form has 2 c x (six times as much -- more than the margin the
+        // schedules allow, which made them diverge).
+        const bool quintic = c.c != 0.f;
+        const float alpha = quintic ? -c.b / (2.f * c.c) : 0.f, gamma = quintic ? c.a - c.b * c.b / (4.f * c.c) : 0.f;
+        bool shifted = false;
+        if (sidx == 0 || !quintic) {
+            CHK(gram(x.Xt, rows, l, w, nullptr, stream));
+        } else {
+            CHK(gram(x.Xt, rows, l, w, w.G16, stream, alpha, &shifted));   // the reduction writes bf16(G - alpha I) directly
+        }
         if (sidx == 0) {
             fro_partial_kernel<<<dim3(FRO_BLOCKS, w.batch), 256, 0, st>>>(w.G, sG, w.fro_part);
             SLIM_LAUNCH_CHECK();
             fro_rsqrt_kernel<<<w.batch, 64, 0, st>>>(w.fro_part, w.scal);
             SLIM_LAUNCH_CHECK();
         }
+        if (quintic && !shifted) {
+            shifted_gram_bf16_kernel<<<pgrid, 256, 0, st>>>(w.G, sidx == 0 ? w.scal : nullptr, alpha, l, w.G16);
+            SLIM_LAUNCH_CHECK();
+        }
         if (quintic) {
-            // G G with the polynomial evaluated in the product's epilogue: P = c (a I + b c^2 G + q c^4 G G) as bf16
+            // P = s (gamma I + c A A), A = bf16(s^2 G - alpha I), evaluated in the product's epilogue
             GemmArgs pg;
             pg.A = w.G16;
             pg.lda = l;
@@ -492,16 +509,17 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
             pg.ldc16 = l;
             pg.batch = w.batch;
             pg.sA = pg.sB = pg.sC16 = sG;
-            pg.poly_G = w.G;
+            pg.poly_G = w.G;            // marks the polynomial epilogue; not read (poly_b == 0)
             pg.poly_sG = sG;
             pg.poly_scal = sidx == 0 ? w.scal : nullptr;
             pg.poly_sScal = SCAL_STRIDE;
-            pg.poly_a = 3.4445f;
-            pg.poly_b = -4.7750f;
-            pg.poly_q = 2.0315f;
+            pg.poly_a = gamma;
+            pg.poly_b = 0.f;
+            pg.poly_q = c.c;
+            pg.poly_prescaled = 1;
             CHK(slim_gemm_launch(pg, stream));
         } else {
-            ns_poly_kernel<<<pgrid, 256, 0, st>>>(w.G, w.G2, sidx == 0 ? w.scal : nullptr, 1.5f, -0.5f, 0.f, l, w.T16);
+            ns_poly_kernel<<<pgrid, 256, 0, st>>>(w.G, w.G2, sidx == 0 ? w.scal : nullptr, c.a, c.b, 0.f, l, w.T16);
             SLIM_LAUNCH_CHECK();
         }
         // P is symmetric, so it serves as its own transpose in the NT product X P
@@ -512,30 +530,60 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, int nq, int nc, Fit
     return SLIM_OK;
 }
 
+// Steps of one Newton-Schulz orthonormalisation of the fit.  cond_e: log2 of the conditioning of the iterate (largest /
+// smallest singular value inside the subspace) the caller expects.
+//   1. A step with the fixed coefficients (3.4445, -4.7750, 2.0315): it takes any singular value of the Frobenius-scaled
+//      iterate (largest anywhere in [l^(-1/4), 1]) into [0.65, 1.2] or lifts it 3.44x, i.e. it pins the top of the
+//      spectrum next to 1 whatever the scaling lost.
+//   2. More such steps while the conditioning that is left exceeds 16 (each gains 3.44 / 1.2 = 2.87x).  The minimax
+//      polynomials are not used there on purpose: on a wide interval they take some mid-range singular values down to the
+//      bottom of their image interval (equi-oscillation), and a direction held at 1/k of the largest one in bf16 picks up
+//      k / 512 of noise -- harmless for k <= 4, ruinous for k in the hundreds.
+//   3. The minimax schedule for what is left (kNsSchedule, rescaled for singular values up to 1.25): `enough` steps for an
+//      intermediate basis, all of them for the last basis before the Rayleigh-Ritz step.
+#define NS_MAX_STEPS 24
+static int build_ns_steps(int cond_e, bool final_pass, NsStep* out) {
+    const NsStep fixed{3.4445f, -4.7750f, 2.0315f};
+    int n = 0;
+    out[n++] = fixed;
+    double kap = exp2((double)cond_e);
+    while (kap > 16.0 && n < NS_MAX_STEPS - NS_SCHED_MAX_STEPS) {
+        out[n++] = fixed;
+        kap /= 2.87;
+    }
+    int es = (int)ceil(log2(kap));
+    es = es < 1 ? 1 : (es > 4 ? 4 : es);
+    const NsSchedule& sc = kNsSchedule[es];
+    const int cnt = final_pass ? sc.total : sc.enough;
+    // the schedule's first polynomial expects singular values up to 1: it is applied to x / 1.25 (the fixed steps leave
+    // them below 1.2); the later ones take the image interval of their predecessor as it is
+    const float h = 1.25f, h3 = h * h * h, h5 = h3 * h * h;
+    for (int i = 0; i < cnt; ++i)
+        out[n++] = i == 0 ? NsStep{sc.step[i].a / h, sc.step[i].b / h3, sc.step[i].c / h5} : sc.step[i];
+    return n;
+}
+
 // one orthonormalisation in the selected mode; cur/out index the rotating buffers
-static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, int nq, FitWs& w, int info_idx,
+static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, int cond_e, FitWs& w, int info_idx,
                 void* stream, int* out_idx) {
-    if (flags & SLIM_FIT_CHOLESKY_QR) {
-        const int nxt = (cur + 1) % 3;
-        CHK(cholesky_qr(bufs[cur], bufs[nxt], rows, l, w, info_idx, stream));
+    NsStep steps[NS_MAX_STEPS];
+    if ((flags & SLIM_FIT_CHOLESKY_QR) || (final_pass && (flags & SLIM_FIT_EXACT_FINAL))) {
+        int mid = cur;
+        if (!(flags & SLIM_FIT_CHOLESKY_QR))   // exact final: condition the basis first, then factorise
+            CHK(ns_orth(bufs, cur, rows, l, steps, build_ns_steps(cond_e, false, steps), w, stream, &mid));
+        const int nxt = (mid + 1) % 3;
+        CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
         *out_idx = nxt;
         return SLIM_OK;
     }
-    if (!final_pass) return ns_orth(bufs, cur, rows, l, nq, 0, w, stream, out_idx);
-    // last basis before the Rayleigh-Ritz step: the polynomial iteration leaves the singular values within [0.68, 1.13];
-    // an fp32 inverse-square-root polish (or, on request, an exact Cholesky-QR) brings them to 1
-    // The polish converges only on a basis that is already well conditioned in EVERY direction (an eigenvalue x of the
-    // Gram matrix moves as x (3 - x)^2 / 4 per step), while nq steps are sized for the conditioning inside the leading
-    // subspace; on small layers, where l is a large part of min(N, K), the weakest directions of the last iterate are
-    // far below that.  Three more quintic steps (a factor 40 each way) before the polish cover them.
-    const bool exact = (flags & SLIM_FIT_EXACT_FINAL) != 0;
-    int mid = cur;
-    CHK(ns_orth(bufs, cur, rows, l, exact ? nq : nq + 3, 0, w, stream, &mid));
-    const int nxt = (mid + 1) % 3;
-    if (exact) CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
-    else CHK(invsqrt_qr(bufs[mid], bufs[nxt], rows, l, w, stream));
-    *out_idx = nxt;
-    return SLIM_OK;
+    // An intermediate basis only has to be well conditioned (the next product with the matrix spreads its singular
+    // values again); the last one before the Rayleigh-Ritz step runs the schedule to its end, which leaves the singular
+    // values within 0.5 % of 1 -- the accuracy a bf16 basis can hold.  On small layers, where l is a large part of
+    // min(N, K), the weakest directions of the last iterate are far below the conditioning the caller's estimate covers:
+    // the last pass allows for a factor 32 more there, and for a factor 4 when l is at most a quarter of the rows.
+    const int extra = 4 * (int64_t)l > rows ? 5 : 2;
+    const int e = final_pass ? (cond_e + extra > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : cond_e + extra) : cond_e;
+    return ns_orth(bufs, cur, rows, l, steps, build_ns_steps(e, final_pass, steps), w, stream, out_idx);
 }
 
 extern "C" int64_t slim_orthonormalize_workspace_bytes(int64_t rows, int64_t l) {
@@ -561,7 +609,12 @@ extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t r
         CHK(cholesky_qr(w.A[0], w.A[1], rows, l, w, 0, stream));
         a = 1;
     } else {
-        CHK(ns_orth(w.A, 0, rows, l, ns_quintic, ns_cubic, w, stream, &a));
+        // fixed coefficients: quintic steps (fast, settle in [0.68, 1.13]), then cubic ones (quadratic convergence to 1)
+        SLIM_REQUIRE(ns_quintic >= 0 && ns_cubic >= 0 && ns_quintic + ns_cubic <= 32, "slim_orthonormalize_bf16: bad step counts");
+        NsStep steps[32];
+        for (int i = 0; i < ns_quintic + ns_cubic; ++i)
+            steps[i] = i < ns_quintic ? NsStep{3.4445f, -4.7750f, 2.0315f} : NsStep{1.5f, -0.5f, 0.f};
+        CHK(ns_orth(w.A, 0, rows, l, steps, ns_quintic + ns_cubic, w, stream, &a));
     }
     SLIM_HIP(hipMemcpyAsync(Q, w.A[a].X, bytes, hipMemcpyDeviceToDevice, st));
     SLIM_HIP(hipMemcpyAsync(Qt, w.A[a].Xt, bytes, hipMemcpyDeviceToDevice, st));
@@ -605,7 +658,8 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     float* sk_slab = (flags & SLIM_FIT_NO_SKETCH_SPLIT) ? nullptr : w.sketch_slab;
     if (flags & SLIM_FIT_NO_SKETCH_SPLIT) w.gram_cap = GRAM_SPLITS_SHARED_CHIP;
     int ninfo = 0, a = 0, b = 0;
-    const int nq = ns_steps > 0 ? (ns_steps > 16 ? 16 : ns_steps) : 4;
+    // ns_steps: log2 of the conditioning the orthonormalisations must cover (0: 2^9)
+    const int nq = ns_steps > 0 ? (ns_steps > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : ns_steps) : 9;
     // when the subspace is the whole space the basis must be orthonormal to working precision in every
     // direction, however weak: take the exact factorisation
     if (l == N || l == K) flags |= SLIM_FIT_CHOLESKY_QR;
@@ -632,14 +686,7 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     for (int it = 0; it < n_iter; ++it) {
         // Z = E^T Q ; P = orth(Z)
         CHK(sketch_cols(w.A[a].Xt));
-        if (flags & SLIM_FIT_ONE_SIDED) {
-            // Z goes into the next product as it is: only the row-side iterate is re-orthonormalised, once per
-            // full iteration (its conditioning is then the square of the matrix's within the subspace, which
-            // the caller's ns_steps has to cover)
-            b = 0;
-        } else {
-            CHK(orth(w.B, 0, K, l, false, flags, nq, w, ninfo, stream, &b));
-        }
+        CHK(orth(w.B, 0, K, l, false, flags, nq, w, ninfo, stream, &b));
         ninfo += 2;
         // Y = E P ; Q = orth(Y)
         CHK(sketch_rows(w.B[b].Xt));

@@ -22,12 +22,6 @@ FIT_SEED = 0
 FIT_CHOLESKY_QR = os.environ.get("SLIM_FIT_CHOLESKY_QR", "0") == "1"
 
 
-# Re-orthonormalise only the row-side iterate, once per full subspace iteration (the column-side product
-# E^T Q feeds the next product as it is).  Its conditioning is then the square of the matrix's conditioning
-# within the subspace, so each orthonormalisation takes more Newton-Schulz steps, but there are half as many.
-# Off by default: measured on MI355X it does not shorten a block (the step is bound by the number of kernel
-# dispatches, most of them the eigen-solver's) and costs up to 1e-3 of reconstruction error.
-FIT_ONE_SIDED = os.environ.get("SLIM_FIT_ONE_SIDED", "0") == "1"
 # Rayleigh-Ritz eigenproblem through rocSOLVER syevd instead of the library's own one-launch-per-column solver
 FIT_LIBRARY_EIGH = os.environ.get("SLIM_FIT_LIBRARY_EIGH", "0") == "1"
 # last basis before the Rayleigh-Ritz step finished by Cholesky-QR (rocSOLVER potrf + trtri) instead of the fp32 polish
@@ -37,30 +31,24 @@ FIT_SKETCH_SPLIT = os.environ.get("SLIM_FIT_SKETCH_SPLIT", "1") == "1"
 
 
 def fit_ns_steps(spread):
-    """Newton-Schulz steps per orthonormalisation for the configured scheme."""
-    if not FIT_ONE_SIDED:
-        return ns_steps_for(spread)
+    """log2 of the conditioning the fit's Newton-Schulz orthonormalisations are sized for (the `ns_steps` argument of
+    slim_lowrank_fit), from the spread max(s) / median(s) of the saliency scales that are left after the outlier columns
+    have been split off.  The error matrix is (benign matrix) x diag(s): its largest singular values come from the columns
+    with the largest scale, the bulk from the typical ones, so the conditioning of an iterate inside the leading subspace
+    is of the order of the spread (measured: about a third of it)."""
     import math
-    kappa = (8.0 * max(float(spread), 1.0)) ** 2
-    return int(min(16, max(5, math.ceil(math.log(kappa) / math.log(3.44)))))
-
-
-def ns_steps_for(spread):
-    """Quintic Newton-Schulz steps per orthonormalisation from the spread max(s) / median(s) of the saliency
-    scales.  The error matrix is (benign matrix) x diag(s): its largest singular values come from the columns with
-    the largest scale, the bulk from the typical ones, so the conditioning of an iterate inside the leading
-    subspace is of the order of the spread (measured: 14 at spread ~40).  Each step lifts a singular value by up
-    to 3.44x; three steps are the floor (two fail at a conditioning of 14, tools/fit_accuracy.py).  Intermediate
-    bases only need to be well conditioned -- the last one is finished by an exact Cholesky-QR."""
-    import math
-    kappa = 2.0 * max(float(spread), 4.0)
-    return int(min(12, max(3, math.ceil(math.log(kappa) / math.log(3.44)))))
+    return int(min(12, max(2, math.ceil(math.log2(max(float(spread), 1.0))))))
 
 
 # Columns of the error matrix whose saliency scale exceeds OUTLIER_RATIO x the median are split off and
-# represented exactly before the randomized fit (at most MAX_OUTLIER_COLS of them).  Below that ratio the
-# Newton-Schulz step count (ns_steps_for) absorbs the spread.
-OUTLIER_RATIO = 64.0
+# represented exactly before the randomized fit (at most MAX_OUTLIER_COLS of them): every factor 4 of spread that is
+# left costs each of the fit's ~20 orthonormalisations one more Newton-Schulz step (three tall products), while splitting
+# a handful of columns off costs one pass over the matrix.
+# Splitting a column off spends one of the adapter's directions on that column alone, which is the best use of it only
+# while such columns are few next to the rank: the low ratio applies while they number at most rank / 16 (on a
+# 256 x 512 layer of rank 25, four split-off columns cost 2 % of reconstruction error), the high one always.
+OUTLIER_RATIO = float(os.environ.get("SLIM_OUTLIER_RATIO", "12"))
+OUTLIER_RATIO_ALWAYS = 64.0
 MAX_OUTLIER_COLS = 64
 
 
@@ -86,7 +74,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     if t == 0 or rank - t < 8:
         over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
         fit = ops.lowrank_fit(E, Et, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
-                              cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
+                              cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
         U, Ut, L = fit["U"], fit["Ut"], fit["L"]
         if U.shape[1] != r8:           # rank above the largest multiple of 8 within min(N, K)
             raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
@@ -115,7 +103,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     rf = _round_up8(rank - t)
     over = max(FIT_MIN_OVERSAMPLE, rf // FIT_OVERSAMPLE_DIV)
     fit = ops.lowrank_fit(E2, ops.transpose(E2), rf, over, FIT_ITERS, seed=FIT_SEED, s=s,
-                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
+                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
     LO = ops.scale_rows(Ct, s) if s is not None else Ct
     U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
     L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
@@ -128,7 +116,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
 
 
 def _fit_kwargs(spread, sketch_split=True):
-    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_ONE_SIDED, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL,
+    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL,
                                                     FIT_SKETCH_SPLIT and sketch_split),
                 ns_steps=fit_ns_steps(spread))
 
@@ -266,20 +254,23 @@ def fit_error_matrix_back(p, d, e, Q, vecs, s, tail_info=None):
     return U, ops.transpose(U), L, info
 
 
-def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, ratio=OUTLIER_RATIO):
+def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, rank=None):
     """((indices of the outlier columns padded to a multiple of 8, number of real outliers) or None, spread of
     the remaining scales).  One host synchronisation; the driver precomputes the same quantities for a
-    whole block at once (prune.block_stats)."""
+    whole block at once (prune.block_stats).  rank: the adapter rank of the layer (None: not limiting)."""
     s = torch.sqrt(scaler_row)
     top = torch.topk(s, min(max_cols + 1, s.numel()))
     host = torch.cat([top.values, s.median().reshape(1)]).cpu()
-    return _outliers_from_host(host[:-1].tolist(), float(host[-1]), top.indices, ratio)
+    return _outliers_from_host(host[:-1].tolist(), float(host[-1]), top.indices, rank)
 
 
-def _outliers_from_host(top_vals, median, top_idx, ratio=OUTLIER_RATIO):
+def _outliers_from_host(top_vals, median, top_idx, rank=None):
     """top_vals: the largest scales in decreasing order (one more than may be listed)."""
     median = max(median, 1e-30)
-    t = sum(1 for v in top_vals[:-1] if v > ratio * median)
+    t_always = sum(1 for v in top_vals[:-1] if v > OUTLIER_RATIO_ALWAYS * median)
+    t = sum(1 for v in top_vals[:-1] if v > OUTLIER_RATIO * median)
+    if rank is not None and t > max(int(rank) // 16, t_always):
+        t = t_always
     t_pad = min(_round_up8(t), (len(top_vals) - 1) // 8 * 8)
     t = min(t, t_pad)
     rest = top_vals[t] / median if t < len(top_vals) else 1.0
@@ -414,7 +405,7 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     if use_slim:
         outliers, spread = getattr(activations, "outliers", "unset"), getattr(activations, "scale_spread", None)
         if spread is None or isinstance(outliers, str):      # not precomputed by the driver
-            outliers, spread = outlier_columns(activations.scaler_row)
+            outliers, spread = outlier_columns(activations.scaler_row, rank=c.rank)
     else:
         outliers, spread = None, 1.0
     c.outliers, c.spread = outliers, spread
@@ -520,7 +511,7 @@ def add_lora_fit(ctxs, E_group=None, Et_group=None):
     over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
     s = torch.stack([c.s for c in ctxs]).contiguous() if ctxs[0].s is not None else None
     fit = ops.lowrank_fit(E_group, Et_group, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
-                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=max(fit_ns_steps(c.spread) for c in ctxs), one_sided=FIT_ONE_SIDED, library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
+                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=max(fit_ns_steps(c.spread) for c in ctxs), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
     U, Ut, L = fit["U"], fit["Ut"], fit["L"]
     if U.shape[-1] != r8:
         raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")

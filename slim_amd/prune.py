@@ -62,12 +62,15 @@ def _streams_for(dev, n):
     return _side_streams[key]
 
 
-def block_stats(wrapped_list):
+def block_stats(wrapped_list, rank_of=None):
     """Per-linear scalars the host needs before compressing a block, fetched with ONE synchronisation:
     has_zero (the any(scaler_row == 0) guard), the indices of outlier channels (saliency scale far above the
     median, which the low-rank fit deflates) and the spread of the remaining scales (sizes the Newton-Schulz
-    orthonormalisation)."""
+    orthonormalisation).  rank_of: callable(wrapped) -> adapter rank of that linear (default: a tenth of its smaller
+    dimension, the recipe's ratio), which limits how many columns are split off."""
     from .lora import MAX_OUTLIER_COLS, _outliers_from_host
+    if rank_of is None:
+        rank_of = lambda w: max(1, min(w.rows, w.columns) // 10)
     if not wrapped_list:            # a rank that owns no linear of this block
         return
     rows, idxs = [], []
@@ -81,7 +84,7 @@ def block_stats(wrapped_list):
     host = torch.stack(rows).cpu()
     for w, row, (idx, k) in zip(wrapped_list, host.tolist(), idxs):
         w.has_zero = bool(row[0])
-        w.outliers, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx)
+        w.outliers, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx, rank_of(w))
 
 
 # SLIM_STREAM_TRACE=1: run_on_streams records, per job, when its host thread started / finished enqueueing and when its
@@ -567,7 +570,10 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         if STATS_CALLBACK is not None:
             for name in subset:
                 STATS_CALLBACK(i, name, wrapped_layers[name])
-        block_stats(list(wrapped_layers.values()))
+        from .lora import lora_rank as _rank_rule
+        tile_rule = lora_tile_size if (quantize_lora or pad_lora) else None
+        block_stats(list(wrapped_layers.values()),
+                    (lambda w: min(_rank_rule((w.rows, w.columns), lora_rank, tile_rule), w.rows, w.columns)) if lora_rank > 0. else None)
 
         names = list(subset)
         owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)

@@ -20,8 +20,8 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=512)
-    ap.add_argument("--configs", default="128:8:4:0,128:8:3:0,128:9:3:0,128:10:3:0,128:8:2:0,128:10:2:0",
-                    help="comma list of oversample:iterations:ns_steps:one_sided")
+    ap.add_argument("--configs", default="128:8:7,128:8:5,128:10:7,128:10:5,128:10:4,128:10:3",
+                    help="comma list of oversample:iterations:log2 of the conditioning the orthonormalisations cover")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.load()
@@ -42,15 +42,15 @@ def main():
     opt = float(torch.sqrt((sv[r:] ** 2).sum()))
     print(f"{N}x{K} rank {r}: sigma_1/sigma_r = {float(sv[0] / sv[r - 1]):.2f}, sigma_r/sigma_(r+128) = {float(sv[r - 1] / sv[r + 127]):.4f}, optimum {opt:.4f}")
     for cfg in args.configs.split(","):
-        over, iters, ns, one = (int(v) for v in cfg.split(":"))
-        ops.lowrank_fit(E, Et, r, over, 1, seed=0, ns_steps=ns, one_sided=bool(one))       # warm
+        over, iters, ns = (int(v) for v in cfg.split(":"))
+        ops.lowrank_fit(E, Et, r, over, 1, seed=0, ns_steps=ns)       # warm
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fit = ops.lowrank_fit(E, Et, r, over, iters, seed=0, ns_steps=ns, one_sided=bool(one))
+        fit = ops.lowrank_fit(E, Et, r, over, iters, seed=0, ns_steps=ns)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         err = float(torch.norm(Ef - fit["U"].float() @ fit["L"].float().t()))
-        print(f"  oversample {over:4d} iterations {iters} ns_steps {ns} one_sided {one}: excess over optimum {err / opt - 1:.2e}   {dt * 1e3:.1f} ms  info {int(fit['info'].abs().sum())}")
+        print(f"  oversample {over:4d} iterations {iters} conditioning 2^{ns}: excess over optimum {err / opt - 1:.2e}   {dt * 1e3:.1f} ms  info {int(fit['info'].abs().sum())}")
 
 
 if __name__ == "__main__":
