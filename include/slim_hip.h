@@ -194,7 +194,8 @@ void slim_gemm_set_trace(void* buf, int capacity_workgroups);
  * given, destroyed), n a multiple of 4 in [4, 2048].  On return row n-1-i of G is the eigenvector of the i-th
  * largest eigenvalue for i < top; info[0] = status of the tridiagonal solver (0 = converged).  This is the
  * Rayleigh-Ritz step of slim_lowrank_fit (the part of torch.svd at slim/lora.py:172 that remains after the
- * subspace iteration): Householder tridiagonalisation with one launch per column, rocSOLVER stedc, one GEMM. */
+ * subspace iteration): Householder tridiagonalisation with one launch per column, then the tridiagonal problem in double
+ * precision (see slim_eigh_tail_f32), one fp32 GEMM. */
 int64_t slim_eigh_workspace_bytes(int n);
 /* The first stage alone (no library call): Householder reduction Q^T A Q = tridiag(d, e) of a symmetric fp32 matrix
  * A [n, n] (destroyed), one launch per column; Q [n, n] row-major, e holds n - 1 values, workspace of 5 n floats. */
@@ -204,11 +205,21 @@ int slim_tridiagonalize_f32(float* A, int n, float* d, float* e, float* Q, void*
  * 5 n floats per problem.  Several layers' fits share it (see slim_lowrank_fit_front / _back). */
 int slim_tridiagonalize_f32_batched(float* A, int n, int batch, float* d, float* e, float* Q, void* workspace,
                                     int64_t workspace_bytes, void* stream);
-/* second stage for one problem: rocSOLVER stedc on (d, e) -- d becomes the eigenvalues, ascending -- and rows
- * n-top .. n-1 of vecs [n, n] = eigenvectors of the `top` largest eigenvalues (Q times the tridiagonal ones).
- * info: device status word.  workspace: n * n floats. */
+/* second stage: the eigenvalues of tridiag(d, e) by multisection on Sturm counts and the wanted eigenvectors by twisted
+ * factorisations, both in double precision, then Q times them on the fp32 matrix cores.  d becomes the eigenvalues,
+ * ascending; rows n-top .. n-1 of vecs [n, n] = eigenvectors of the `top` largest eigenvalues of the original matrix.
+ * info: device status word per problem (0 = fine).  The batched form takes d / e [batch][n], Q / vecs [batch][n, n],
+ * info [batch] and solves all problems in three launches. */
+int64_t slim_eigh_tail_workspace_bytes(int n, int top, int batch);
 int slim_eigh_tail_f32(float* d, float* e, const float* Q, int n, int top, float* vecs, int32_t* info, void* workspace,
                        int64_t workspace_bytes, void* stream);
+int slim_eigh_tail_f32_batched(float* d, float* e, const float* Q, int n, int batch, int top, float* vecs, int32_t* info,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+/* C [M, N] (fp32, row stride ldc) = alpha * a b on the fp32 matrix cores, a [M, Kd], b [Kd, N]; a_kmajor: A is stored
+ * [Kd, M] (row stride lda), else [M, Kd]; b_kmajor: B is stored [Kd, N] (row stride ldb), else [N, Kd].  Sizes and strides
+ * multiples of 4.  The eigen-solver's back-product; no counterpart in the reference (inside torch.svd, slim/lora.py:172). */
+int slim_gemm_f32(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, int M, int N, int Kd,
+                  float alpha, float* C, int64_t ldc, void* stream);
 int slim_eigh_f32(float* G, int n, int top, float* evals, int32_t* info, void* workspace, int64_t workspace_bytes,
                   void* stream);
 

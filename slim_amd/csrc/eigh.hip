@@ -12,12 +12,20 @@
 //       dot products with the new v (the next p), and
 //   (4) multiplies its share of the rows of the accumulated orthogonal matrix Q by reflector j (Q <- Q H_j is
 //       row-local, so no back-transformation pass over n reflectors is needed afterwards).
-// The tridiagonal problem then goes to rocSOLVER's divide-and-conquer solver (stedc) and the wanted eigenvectors
-// are Q times its eigenvectors (one fp32 GEMM).
+// The tridiagonal problem is then solved in double precision, whole batch at once, in two launches: every eigenvalue by
+// multisection on Sturm counts (a wavefront per eigenvalue, 64 shifts per sweep), every wanted eigenvector by a twisted
+// factorisation at its eigenvalue (a thread per eigenvector).  The matrix is only known to fp32 accuracy, so eigenvalues
+// that coincide to fp32 rounding are still ~1e7 units of double rounding apart: each vector is resolved on its own and
+// no re-orthogonalisation inside clusters is needed.  The wanted eigenvectors of the dense matrix are Q times the
+// tridiagonal ones (one fp32 MFMA GEMM, f32gemm.hip).  SLIM_EIGH_LIBRARY_TAIL=1 sends the tridiagonal problem to
+// rocSOLVER's divide-and-conquer solver (stedc) and rocBLAS instead.
 #include "common.hpp"
 #include "../../include/slim_hip.h"
 #include "eigh.hpp"
 #include "solver.hpp"
+#include "f32gemm.hpp"
+#include <cfloat>
+#include <cstdlib>
 
 #define TD_THREADS 256
 #define TD_ROWS_PER_WAVE 2
@@ -261,11 +269,231 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_step_kernel(TridiagArgs g)
     }
 }
 
+
+// ---- tridiagonal eigen-solver in double precision -------------------------------------------------------------------
+// Number of eigenvalues of tridiag(d, e) that are <= x (LAPACK dstebz's count: negative pivots of the LDL^T factorisation
+// of T - x I, a pivot smaller than pivmin in magnitude counted as negative).  e2[i] = e[i]^2.
+__device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n, double x,
+                                           double pivmin) {
+    double q = d[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    int cnt = q <= 0.0;
+    for (int i = 1; i < n; ++i) {
+        q = d[i] - x - e2[i - 1] / q;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += q <= 0.0;
+    }
+    return cnt;
+}
+
+struct TriEigArgs {
+    const float* d;     // [batch][n]
+    const float* e;     // [batch][n] (n - 1 used)
+    double* lam;        // [batch][n] eigenvalues, ascending (workspace)
+    float* evals;       // [batch][n] the same rounded to fp32
+    double* lplus;      // [batch][n][ldz]
+    double* uminus;     // [batch][n][ldz]
+    double* zbuf;       // [batch][n][ldz]
+    float* Z;           // [batch][n][ldz]: column m holds the eigenvector of eigenvalue n - ldz + m
+    int* info;          // status word per problem (stride info_stride): bit 0 set = a vector overflowed
+    int n, ldz, info_stride;
+};
+
+// one wavefront per eigenvalue: the interval [lo, hi] that holds eigenvalue k shrinks 65-fold per sweep
+__global__ __launch_bounds__(256) void tri_multisect_kernel(TriEigArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double sd[];      // d [n], e2 [n]
+    __shared__ double red[8];
+    const int n = g.n, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t bz = blockIdx.y;
+    const float* d32 = g.d + bz * n;
+    const float* e32 = g.e + bz * n;
+    double* d = sd;
+    double* e2 = sd + n;
+    double gl = DBL_MAX, gu = -DBL_MAX, emax = 0.0;
+    for (int i = t; i < n; i += 256) {
+        const double di = (double)d32[i];
+        const double el = i > 0 ? fabs((double)e32[i - 1]) : 0.0, er = i < n - 1 ? fabs((double)e32[i]) : 0.0;
+        d[i] = di;
+        e2[i] = er * er;
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+        emax = fmax(emax, er * er);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, o, 64));
+        gu = fmax(gu, __shfl_xor(gu, o, 64));
+        emax = fmax(emax, __shfl_xor(emax, o, 64));
+    }
+    if (lane == 0) {
+        red[wave] = gl;
+        red[4 + wave] = gu;
+    }
+    __shared__ double red_e[4];
+    if (lane == 0) red_e[wave] = emax;
+    __syncthreads();
+    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    gu = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    emax = fmax(fmax(red_e[0], red_e[1]), fmax(red_e[2], red_e[3]));
+    const double norm = fmax(fabs(gl), fabs(gu));
+    const double pivmin = DBL_MIN * fmax(1.0, emax);
+    const double slack = 2.0 * DBL_EPSILON * norm * n + 2.0 * pivmin;
+    const int k = (int)blockIdx.x * 4 + wave;        // eigenvalue index, ascending
+    if (k >= n) return;
+    double lo = gl - slack, hi = gu + slack;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double w = hi - lo;
+        if (w <= 2.0 * DBL_EPSILON * norm + 2.0 * pivmin) break;     // accuracy relative to the matrix, as the vectors need it
+        const double x = lo + w * ((double)(lane + 1) / 65.0);
+        const int cnt = sturm_count(d, e2, n, x, pivmin);
+        // eigenvalue k is the smallest x with count(x) >= k + 1: the first lane that reaches the count bounds it from above
+        const unsigned long long ok = __ballot(cnt >= k + 1);
+        const int f = ok ? __ffsll((long long)ok) - 1 : 64;
+        const double xf = __shfl(x, f < 64 ? f : 63, 64), xp = __shfl(x, f > 0 ? f - 1 : 0, 64);
+        const double nhi = f < 64 ? xf : hi, nlo = f > 0 ? xp : lo;
+        hi = nhi;
+        lo = nlo;
+    }
+    if (lane == 0) {
+        const double lam = 0.5 * (lo + hi);
+        g.lam[bz * n + k] = lam;
+        g.evals[bz * n + k] = (float)lam;
+    }
+}
+
+// one thread per wanted eigenvector: twisted factorisation of T - lam I (forward L D L^T and backward U D U^T pivots, joined
+// at the index where they fit best), which gives the eigenvector of an isolated eigenvalue to high relative accuracy in
+// one pass, without iteration or starting vector
+__global__ __launch_bounds__(64) void tri_twisted_kernel(TriEigArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double sd[];      // d [n], e [n]
+    const int n = g.n, ldz = g.ldz, t = threadIdx.x;
+    const int64_t bz = blockIdx.y;
+    double* d = sd;
+    double* e = sd + n;
+    double nrm = 0.0;
+    for (int i = t; i < n; i += 64) {
+        d[i] = (double)g.d[bz * n + i];
+        e[i] = i < n - 1 ? (double)g.e[bz * n + i] : 0.0;
+        nrm = fmax(nrm, fabs(d[i]) + 2.0 * fabs(e[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o, 64));
+    __syncthreads();
+    const int col = (int)blockIdx.x * 64 + t;        // column of Z
+    if (col >= ldz) return;
+    const int m = n - ldz + col;                     // eigenvalue index
+    const double* lamv = g.lam + bz * n;
+    const double lam = lamv[m];
+    double* lp = g.lplus + bz * n * ldz + col;
+    double* um = g.uminus + bz * n * ldz + col;
+    double* zb = g.zbuf + bz * n * ldz + col;
+    const double tiny = fmax(nrm, DBL_MIN * 1e30) * 1e-30;       // a zero pivot is a shift of the eigenvalue by this much
+    // forward pivots D+ (kept in zb) and multipliers
+    double dp = d[0] - lam;
+    for (int i = 0; i < n - 1; ++i) {
+        if (fabs(dp) < tiny) dp = dp < 0.0 ? -tiny : tiny;
+        zb[(int64_t)i * ldz] = dp;
+        const double l = e[i] / dp;
+        lp[(int64_t)i * ldz] = l;
+        dp = (d[i + 1] - lam) - l * e[i];
+    }
+    if (fabs(dp) < tiny) dp = dp < 0.0 ? -tiny : tiny;
+    zb[(int64_t)(n - 1) * ldz] = dp;
+    // how many eigenvalues below this one coincide with it to rounding: copies of an eigenvalue of a matrix that splits
+    // into blocks each take another of the equally good twist indices, so that their vectors sit in different blocks
+    int dup = 0;
+    for (int j = m - 1; j >= 0 && fabs(lamv[j] - lam) <= 16.0 * DBL_EPSILON * nrm; --j) ++dup;
+    // backward pivots D- and multipliers; gamma_i = D+_i + D-_i - (d_i - lam), twist at the smallest |gamma|
+    int kbest = n - 1;
+    double gbest = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double dm = d[n - 1] - lam;
+        int seen = 0;
+        double best = fabs(zb[(int64_t)(n - 1) * ldz]);
+        if (pass == 1 && best <= gbest * (1.0 + 1e-6) + tiny) {
+            if (seen == dup) kbest = n - 1;
+            ++seen;
+        }
+        if (pass == 0) kbest = n - 1;
+        for (int i = n - 2; i >= 0; --i) {
+            if (fabs(dm) < tiny) dm = dm < 0.0 ? -tiny : tiny;
+            const double u = e[i] / dm;
+            if (pass == 0) um[(int64_t)i * ldz] = u;
+            dm = (d[i] - lam) - u * e[i];
+            const double gam = fabs(zb[(int64_t)i * ldz] + dm - (d[i] - lam));
+            if (pass == 0) {
+                if (gam < best) {
+                    best = gam;
+                    kbest = i;
+                }
+            } else if (gam <= gbest * (1.0 + 1e-6) + tiny) {
+                if (seen == dup) kbest = i;
+                ++seen;
+            }
+        }
+        if (pass == 0) gbest = best;
+        if (dup == 0) break;
+    }
+    // the vector: 1 at the twist, multipliers outwards
+    double z = 1.0, ss = 1.0;
+    zb[(int64_t)kbest * ldz] = 1.0;
+    for (int i = kbest - 1; i >= 0; --i) {
+        z = -lp[(int64_t)i * ldz] * z;
+        zb[(int64_t)i * ldz] = z;
+        ss += z * z;
+    }
+    z = 1.0;
+    for (int i = kbest; i < n - 1; ++i) {
+        z = -um[(int64_t)i * ldz] * z;
+        zb[(int64_t)(i + 1) * ldz] = z;
+        ss += z * z;
+    }
+    const bool finite = ss < DBL_MAX && ss == ss;
+    if (!finite) atomicOr(g.info + bz * g.info_stride, 1);
+    const double inv = finite ? 1.0 / sqrt(ss) : 0.0;
+    float* Zc = g.Z + bz * n * ldz + col;
+    for (int i = 0; i < n; ++i) Zc[(int64_t)i * ldz] = (float)(zb[(int64_t)i * ldz] * inv);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 
+// workspace of the tridiagonal stage for `batch` problems with ldz wanted vectors each
+struct TailWs {
+    double *lam, *lplus, *uminus, *zbuf;
+    float *dcopy, *Z, *C;      // C: n x n scratch of the library path
+    int64_t total;
+};
+static TailWs tail_ws(char* base, int n, int ldz, int batch) {
+    TailWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) {
+        char* p = base ? base + o : nullptr;
+        o += al256(bytes * batch);
+        return p;
+    };
+    w.lam = (double*)take((int64_t)n * 8);
+    w.lplus = (double*)take((int64_t)n * ldz * 8);
+    w.uminus = (double*)take((int64_t)n * ldz * 8);
+    w.zbuf = (double*)take((int64_t)n * ldz * 8);
+    w.dcopy = (float*)take((int64_t)n * 4);
+    w.Z = (float*)take((int64_t)n * ldz * 4);
+    w.C = w.Z;                 // the library path needs n x n floats: callers size ldz = n for it
+    w.total = o;
+    return w;
+}
+static inline int round_up4(int v) { return (v + 3) & ~3; }
+static bool library_tail() {
+    static const bool on = [] {
+        const char* v = getenv("SLIM_EIGH_LIBRARY_TAIL");
+        return v && v[0] == '1';
+    }();
+    return on;
+}
+
 struct EighWs {
-    float *Q, *C, *e, *vbuf, *pbuf, *taus;
+    float *Q, *e, *vbuf, *pbuf, *taus;
+    char* tail;
     int64_t total;
 };
 static EighWs eigh_ws(char* base, int n, int batch) {
@@ -277,21 +505,17 @@ static EighWs eigh_ws(char* base, int n, int batch) {
         return (float*)p;
     };
     w.Q = take((int64_t)n * n * 4);
-    w.C = take((int64_t)n * n * 4);
     w.e = take((int64_t)n * 4);
     w.vbuf = take((int64_t)2 * n * 4);
     w.pbuf = take((int64_t)2 * n * 4);
     w.taus = take((int64_t)n * 4);
+    w.tail = base ? base + o : nullptr;
+    o += tail_ws(nullptr, n, n, batch).total;
     w.total = o;
     return w;
 }
 
-bool slim_eigh_supported(int n) {
-    rb_handle h = nullptr;
-    if (n < 3 || n > SLIM_EIGH_MAX_N || n % 4 != 0) return false;
-    if (solver_handle(nullptr, &h) != SLIM_OK) return false;
-    return g_solver.stedc && g_solver.sgemm;
-}
+bool slim_eigh_supported(int n) { return n >= 4 && n <= SLIM_EIGH_MAX_N && n % 4 == 0; }
 
 int64_t slim_eigh_ws_bytes(int n, int batch) { return eigh_ws(nullptr, n, batch).total; }
 
@@ -326,43 +550,89 @@ static int tridiagonalize(float* A, float* Q, float* vbuf, float* pbuf, float* t
     return SLIM_OK;
 }
 
-int slim_eigh_launch(float* G, int n, int batch, int top, float* evals, int* info, int info_stride, void* ws,
-                     int64_t ws_bytes, hipStream_t st) {
-    SLIM_REQUIRE(G && evals && info && ws && batch >= 1 && batch <= 65535, "slim_eigh: bad arguments");
-    SLIM_REQUIRE(n >= 3 && n <= SLIM_EIGH_MAX_N && n % 4 == 0, "slim_eigh: n must be a multiple of 4 in [4, 2048]");
-    SLIM_REQUIRE(top >= 1 && top <= n, "slim_eigh: bad number of wanted eigenvectors");
-    SLIM_REQUIRE(((uintptr_t)G % 16) == 0 && ((uintptr_t)ws % 16) == 0, "slim_eigh: buffers must be 16-byte aligned");
-    SLIM_REQUIRE(ws_bytes >= slim_eigh_ws_bytes(n, batch), "slim_eigh: workspace too small");
-    rb_handle h = nullptr;
-    int rc = solver_handle(st, &h);
-    if (rc) return rc;
-    SLIM_REQUIRE(g_solver.stedc && g_solver.sgemm, "slim_eigh: rocsolver_sstedc / rocblas_sgemm not available");
-    EighWs w = eigh_ws((char*)ws, n, batch);
-    rc = tridiagonalize(G, w.Q, w.vbuf, w.pbuf, w.taus, evals, w.e, n, batch, st);
-    if (rc) return rc;
-    {
-        SLIM_PROF("solver_stedc", st, 0.0, 4.0 * n * (double)n * n * batch);
-        for (int b = 0; b < batch; ++b)
-            if (g_solver.stedc(h, RB_EVECT_TRIDIAGONAL, n, evals + (int64_t)b * n, w.e + (int64_t)b * n,
-                               w.C + (int64_t)b * n * n, n, info + (int64_t)b * info_stride) != 0) {
-                slim_set_error("rocsolver_sstedc failed");
-                return SLIM_ERR_SOLVER;
-            }
-    }
-    {
-        // eigenvector k of G = Q c_k.  Column-major view: the buffer holding row-major Q is Q^T, the solver's C holds c_k
-        // as column k, and column k of the product lands where the row-major result keeps "row k = eigenvector k".
-        SLIM_PROF("eigh_backproduct", st, 0.0, 2.0 * n * (double)n * top * batch);
+// Second stage for `batch` problems: tridiag(d, e) [batch][n] with the reduction's Q [batch][n, n] -> eigenvalues ascending in
+// `evals` (which may be the buffer d), rows n - top .. n - 1 of vecs [batch][n, n] = eigenvectors of the `top` largest
+// eigenvalues of the dense matrix; info[b * info_stride] = status of problem b.
+static int eigh_tail(float* d, float* e, const float* Q, int n, int batch, int top, float* evals, float* vecs, int* info,
+                     int info_stride, char* ws, int64_t ws_bytes, hipStream_t st) {
+    const int ldz = library_tail() ? n : round_up4(top);
+    TailWs w = tail_ws(ws, n, ldz, batch);
+    SLIM_REQUIRE(ws_bytes >= w.total, "slim_eigh: workspace too small");
+    if (library_tail()) {
+        rb_handle h = nullptr;
+        int rc = solver_handle(st, &h);
+        if (rc) return rc;
+        SLIM_REQUIRE(g_solver.stedc && g_solver.sgemm, "slim_eigh: rocsolver_sstedc / rocblas_sgemm not available");
+        if (evals != d) SLIM_HIP(hipMemcpyAsync(evals, d, (size_t)batch * n * sizeof(float), hipMemcpyDeviceToDevice, st));
         const float one = 1.f, zero = 0.f;
         const int64_t off = (int64_t)(n - top) * n;
-        for (int b = 0; b < batch; ++b)
-            if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, n, top, n, &one, w.Q + (int64_t)b * n * n, n,
-                               w.C + (int64_t)b * n * n + off, n, &zero, G + (int64_t)b * n * n + off, n) != 0) {
+        for (int b = 0; b < batch; ++b) {
+            float* C = w.C + (int64_t)b * n * n;
+            {
+                SLIM_PROF("solver_stedc", st, 0.0, 4.0 * n * (double)n * n);
+                if (g_solver.stedc(h, RB_EVECT_TRIDIAGONAL, n, evals + (int64_t)b * n, e + (int64_t)b * n, C, n,
+                                   info + (int64_t)b * info_stride) != 0) {
+                    slim_set_error("rocsolver_sstedc failed");
+                    return SLIM_ERR_SOLVER;
+                }
+            }
+            // eigenvector k of G = Q c_k.  Column-major view: the buffer holding row-major Q is Q^T, the solver's C holds c_k
+            // as column k, and column k of the product lands where the row-major result keeps "row k = eigenvector k".
+            SLIM_PROF("eigh_backproduct", st, 0.0, 2.0 * n * (double)n * top);
+            if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, n, top, n, &one, Q + (int64_t)b * n * n, n, C + off, n, &zero,
+                               vecs + (int64_t)b * n * n + off, n) != 0) {
                 slim_set_error("rocblas_sgemm failed");
                 return SLIM_ERR_SOLVER;
             }
+        }
+        return SLIM_OK;
     }
-    return SLIM_OK;
+    SLIM_HIP(hipMemcpyAsync(w.dcopy, d, (size_t)batch * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    SLIM_HIP(hipMemset2DAsync(info, (size_t)info_stride * sizeof(int), 0, sizeof(int), (size_t)batch, st));
+    TriEigArgs a{w.dcopy, e, w.lam, evals, w.lplus, w.uminus, w.zbuf, w.Z, info, n, ldz, info_stride};
+    {
+        // a sweep evaluates 64 shifts of n pivots each per eigenvalue; about eight sweeps reach double precision
+        SLIM_PROF("eigh_multisect", st, 0.0, 8.0 * 64.0 * 3.0 * n * (double)n * batch);
+        SLIM_HIP(slim_allow_dynamic_lds((const void*)tri_multisect_kernel, 2 * SLIM_EIGH_MAX_N * (int)sizeof(double)));
+        tri_multisect_kernel<<<dim3((unsigned)((n + 3) / 4), (unsigned)batch), 256, (size_t)2 * n * sizeof(double), st>>>(a);
+        SLIM_LAUNCH_CHECK();
+    }
+    {
+        SLIM_PROF("eigh_twisted", st, 44.0 * n * (double)ldz * batch, 12.0 * n * (double)ldz * batch);
+        SLIM_HIP(slim_allow_dynamic_lds((const void*)tri_twisted_kernel, 2 * SLIM_EIGH_MAX_N * (int)sizeof(double)));
+        tri_twisted_kernel<<<dim3((unsigned)((ldz + 63) / 64), (unsigned)batch), 64, (size_t)2 * n * sizeof(double), st>>>(a);
+        SLIM_LAUNCH_CHECK();
+    }
+    // vecs[n - ldz + m][i] = sum_k Z[k][m] Q[i][k]
+    F32GemmArgs g;
+    g.A = w.Z;
+    g.lda = ldz;
+    g.a_kmajor = 1;
+    g.B = Q;
+    g.ldb = n;
+    g.b_kmajor = 0;
+    g.M = ldz;
+    g.N = n;
+    g.Kd = n;
+    g.C = vecs + (int64_t)(n - ldz) * n;
+    g.ldc = n;
+    g.batch = batch;
+    g.sA = (int64_t)n * ldz;
+    g.sB = g.sC = (int64_t)n * n;
+    return slim_f32gemm_launch(g, st);
+}
+
+int slim_eigh_launch(float* G, int n, int batch, int top, float* evals, int* info, int info_stride, void* ws,
+                     int64_t ws_bytes, hipStream_t st) {
+    SLIM_REQUIRE(G && evals && info && ws && batch >= 1 && batch <= 65535, "slim_eigh: bad arguments");
+    SLIM_REQUIRE(n >= 4 && n <= SLIM_EIGH_MAX_N && n % 4 == 0, "slim_eigh: n must be a multiple of 4 in [4, 2048]");
+    SLIM_REQUIRE(top >= 1 && top <= n, "slim_eigh: bad number of wanted eigenvectors");
+    SLIM_REQUIRE(((uintptr_t)G % 16) == 0 && ((uintptr_t)ws % 16) == 0, "slim_eigh: buffers must be 16-byte aligned");
+    SLIM_REQUIRE(ws_bytes >= slim_eigh_ws_bytes(n, batch), "slim_eigh: workspace too small");
+    EighWs w = eigh_ws((char*)ws, n, batch);
+    int rc = tridiagonalize(G, w.Q, w.vbuf, w.pbuf, w.taus, evals, w.e, n, batch, st);
+    if (rc) return rc;
+    return eigh_tail(evals, w.e, w.Q, n, batch, top, evals, G, info, info_stride, w.tail, tail_ws(nullptr, n, n, batch).total, st);
 }
 
 // The reduction alone (no library call): A [n, n] symmetric fp32 (destroyed) -> d [n], e [n] (n - 1 used), Q [n, n]
@@ -389,35 +659,25 @@ extern "C" int slim_tridiagonalize_f32_batched(float* A, int n, int batch, float
     return tridiagonalize(A, Q, ws, ws + (int64_t)2 * n * batch, ws + (int64_t)4 * n * batch, d, e, n, batch, (hipStream_t)stream);
 }
 
-// Second stage for one problem: eigen-decomposition of tridiag(d, e) by rocSOLVER stedc (d becomes the eigenvalues,
-// ascending; e is destroyed) and rows n-top .. n-1 of vecs [n, n] = the eigenvectors of the `top` largest eigenvalues of
-// the original matrix (Q times the tridiagonal ones).  workspace: n * n floats.
+// Second stage for `batch` problems of one size: eigen-decomposition of tridiag(d, e) (d becomes the eigenvalues, ascending;
+// e is read) and rows n-top .. n-1 of vecs [n, n] = the eigenvectors of the `top` largest eigenvalues of the original
+// matrix (Q times the tridiagonal ones).  workspace: slim_eigh_tail_workspace_bytes(n, top, batch).
+extern "C" int64_t slim_eigh_tail_workspace_bytes(int n, int top, int batch) {
+    if (n <= 0 || top <= 0 || batch <= 0) return 0;
+    return tail_ws(nullptr, n, library_tail() ? n : round_up4(top), batch).total;
+}
+extern "C" int slim_eigh_tail_f32_batched(float* d, float* e, const float* Q, int n, int batch, int top, float* vecs,
+                                          int32_t* info, void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(d && e && Q && vecs && info && workspace, "slim_eigh_tail_f32: null pointer");
+    SLIM_REQUIRE(n >= 4 && n <= SLIM_EIGH_MAX_N && n % 4 == 0 && top >= 1 && top <= n && batch >= 1 && batch <= 65535,
+                 "slim_eigh_tail_f32: bad sizes");
+    SLIM_REQUIRE(((uintptr_t)Q % 16) == 0 && ((uintptr_t)vecs % 16) == 0 && ((uintptr_t)workspace % 16) == 0,
+                 "slim_eigh_tail_f32: buffers must be 16-byte aligned");
+    return eigh_tail(d, e, Q, n, batch, top, d, vecs, info, 1, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+}
 extern "C" int slim_eigh_tail_f32(float* d, float* e, const float* Q, int n, int top, float* vecs, int32_t* info, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
-    SLIM_REQUIRE(d && e && Q && vecs && info && workspace, "slim_eigh_tail_f32: null pointer");
-    SLIM_REQUIRE(n >= 3 && n <= SLIM_EIGH_MAX_N && top >= 1 && top <= n, "slim_eigh_tail_f32: bad sizes");
-    SLIM_REQUIRE(workspace_bytes >= (int64_t)n * n * 4, "slim_eigh_tail_f32: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    rb_handle h = nullptr;
-    int rc = solver_handle(st, &h);
-    if (rc) return rc;
-    SLIM_REQUIRE(g_solver.stedc && g_solver.sgemm, "slim_eigh_tail_f32: rocsolver_sstedc / rocblas_sgemm not available");
-    float* C = (float*)workspace;
-    {
-        SLIM_PROF("solver_stedc", st, 0.0, 4.0 * n * (double)n * n);
-        if (g_solver.stedc(h, RB_EVECT_TRIDIAGONAL, n, d, e, C, n, info) != 0) {
-            slim_set_error("rocsolver_sstedc failed");
-            return SLIM_ERR_SOLVER;
-        }
-    }
-    SLIM_PROF("eigh_backproduct", st, 0.0, 2.0 * n * (double)n * top);
-    const float one = 1.f, zero = 0.f;
-    const int64_t off = (int64_t)(n - top) * n;
-    if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, n, top, n, &one, Q, n, C + off, n, &zero, vecs + off, n) != 0) {
-        slim_set_error("rocblas_sgemm failed");
-        return SLIM_ERR_SOLVER;
-    }
-    return SLIM_OK;
+    return slim_eigh_tail_f32_batched(d, e, Q, n, 1, top, vecs, info, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t slim_eigh_workspace_bytes(int n) { return n > 0 ? slim_eigh_ws_bytes(n, 1) : 0; }

@@ -417,16 +417,18 @@ def tridiagonalize_batched(A):
 
 
 def eigh_tail(d, e, Q, vecs, top):
-    """Second stage of the eigen-solver for ONE problem: tridiagonal (d, e) [n] with the reduction's Q [n, n] -> eigenvalues
-    ascending in d, row n-1-i of vecs [n, n] = eigenvector of the i-th largest for i < top.  Returns the status word
-    (int32 [1] on the device, 0 = converged)."""
+    """Second stage of the eigen-solver for all problems of one size in one call: tridiagonal (d, e) [B, n] with the
+    reductions' Q [B, n, n] (a single problem may come without the leading dimension) -> eigenvalues ascending in d, row
+    n-1-i of vecs [B, n, n] = eigenvector of the i-th largest for i < top.  Returns the status words (int32 [B] on the
+    device, 0 = fine)."""
     d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
-    n = d.numel()
-    if e.numel() != n or Q.numel() != n * n or vecs.numel() != n * n:
-        raise ValueError("eigh_tail: operands of one n x n problem expected")
-    info = torch.zeros(1, dtype=torch.int32, device=Q.device)
-    ws = torch.empty(n * n, dtype=torch.float32, device=Q.device)
-    _lib.call("slim_eigh_tail_f32", _p(d), _p(e), _p(Q), n, int(top), _p(vecs), _p(info), _p(ws), ws.numel() * 4, _stream())
+    n = d.shape[-1]
+    B = d.numel() // n
+    if e.numel() != B * n or Q.numel() != B * n * n or vecs.numel() != B * n * n:
+        raise ValueError("eigh_tail: operands of B problems of size n x n expected")
+    info = torch.zeros(B, dtype=torch.int32, device=Q.device)
+    ws = _ws(_lib.query("slim_eigh_tail_workspace_bytes", n, int(top), B), Q.device)
+    _lib.call("slim_eigh_tail_f32_batched", _p(d), _p(e), _p(Q), n, B, int(top), _p(vecs), _p(info), _p(ws), ws.numel(), _stream())
     return info
 
 
@@ -446,12 +448,7 @@ def lowrank_fit_back(ctx, d, e, Q, vecs, s=None, tail_info=None):
         if info1.numel() != B:
             raise ValueError("tail_info must hold one status word per problem")
     else:
-        info1 = torch.zeros(B, dtype=torch.int32, device=dev)
-        ws2 = torch.empty(l * l, dtype=torch.float32, device=dev)
-        dv, ev, Qv, vv = d.reshape(B, l), e.reshape(B, l), Q.reshape(B, l, l), vecs.reshape(B, l, l)
-        for b in range(B):
-            _lib.call("slim_eigh_tail_f32", _p(dv[b]), _p(ev[b]), _p(Qv[b]), l, r, _p(vv[b]), _p(info1[b:]), _p(ws2),
-                      ws2.numel() * 4, _stream())
+        info1 = eigh_tail(d.reshape(B, l), e.reshape(B, l), Q.reshape(B, l, l), vecs.reshape(B, l, l), r)
     if s is not None:
         s = _chk(s, torch.float32, "s")
         if s.numel() != B * K:

@@ -442,15 +442,6 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                     _lora.add_lora_fit_back_group([ctxs[i] for i in members], d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
                 return [x for i in members for x in ctxs[i].tensors()]
 
-            def tail(g, b, tri):
-                # the second stage of a member's eigen-solve (a library call per problem): one job per member, so that the
-                # solves overlap instead of queueing on their group's stream
-                l, b0 = where[g]
-                d, e, Q = tri[l]
-                r_fit = ctxs[fit_groups[g][1][0]].pending["ctx"]["r"]
-                tails[l][b0 + b:b0 + b + 1] = ops.eigh_tail(d[b0 + b], e[b0 + b], Q[b0 + b], Mb[l][b0 + b], r_fit)
-                return [tails[l]]
-
             # (splitting the linears into two groups so that one group's chain overlaps the other's GEMM-heavy halves was
             # measured slower, 56.7 vs 47 ms: the extra barriers cost more than the idle chip during the shared chain)
             ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
@@ -458,10 +449,14 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                 run_on_streams([lambda g=g, b=b: prepare_member(g, b) for g in range(len(fit_groups))
                                 for b in range(len(fit_groups[g][1]))], dev, n_streams)
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
+            # the eigenproblems of the block, size by size: one tridiagonalisation chain and three launches for the
+            # tridiagonal stage, each carrying every problem of that size
             tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
-            tails = {l: torch.zeros(n, dtype=torch.int32, device=dev) for l, n in count.items()}
-            run_on_streams([lambda g=g, b=b: tail(g, b, tri) for g in range(len(fit_groups))
-                            for b in range(len(fit_groups[g][1]))], dev, n_streams)
+            top = {}
+            for g in range(len(fit_groups)):
+                r_fit = ctxs[fit_groups[g][1][0]].pending["ctx"]["r"]
+                top[where[g][0]] = max(top.get(where[g][0], 0), r_fit)
+            tails = {l: ops.eigh_tail(tri[l][0], tri[l][1], tri[l][2], Mb[l], top[l]) for l in sorted(Mb)}
             run_on_streams([lambda g=g: back(g, tri) for g in range(len(fit_groups))], dev, n_streams, ids)
             run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
             return

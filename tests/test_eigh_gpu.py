@@ -1,5 +1,6 @@
-"""The in-library symmetric eigen-solver (one launch per column of the tridiagonalisation, rocSOLVER stedc, one GEMM)
-against numpy.linalg.eigh in float64: eigenvalues, residuals and orthonormality of the leading eigenvectors."""
+"""The in-library symmetric eigen-solver (one launch per column of the tridiagonalisation, the tridiagonal problem by
+multisection and twisted factorisations in double precision, one fp32 GEMM) against numpy.linalg.eigh in float64:
+eigenvalues, residuals and orthonormality of the leading eigenvectors."""
 import numpy as np
 import pytest
 import torch
