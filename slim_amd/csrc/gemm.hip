@@ -753,7 +753,12 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                     : FAM_BIG;
     const int tile = gemm_pick_tile(fam);
     const int BM = kTileM[tile], BN = kTileN[tile];
-    if (g.sym && !(g.splits > 1 && g.M == g.N && BM == BN && g.A == g.B && g.lda == g.ldb && !g.Ct16)) g.sym = 0;
+    // symmetric products: with split-K the reduction mirrors the lower tiles; without it the workgroups of the upper
+    // tiles write their tile and its transpose, which the caller asks for by aiming C^T at C itself (bf16 outputs only)
+    const bool sym_shape = g.M == g.N && BM == BN && g.A == g.B && g.lda == g.ldb;
+    const bool sym_split = g.splits > 1 && !g.Ct16;
+    const bool sym_mirror = g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f;
+    if (g.sym && !(sym_shape && (sym_split || sym_mirror))) g.sym = 0;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");

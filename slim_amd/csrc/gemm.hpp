@@ -29,6 +29,7 @@ struct GemmArgs {
     // symmetric product (A == B, M == N, split-K only): workgroups cover the tiles on and above the diagonal, and the
     // reduction reads the mirrored element for the tiles below it (X^T X computed once per pair of tiles; the mirrored
     // value is what the lower tile would have produced, since every product of the sum commutes)
+    // (without split-K: set Ct16 = C16 and ldct = ldc16; the upper tiles then write themselves and their mirror image)
     int sym = 0;
     // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
     int batch = 1;

@@ -121,14 +121,32 @@ __global__ void ridge_kernel(float* __restrict__ g, int l, float rel) {
 
 // syevd returns eigenvalues ascending and eigenvectors as columns (column-major), i.e. row i of the
 // row-major view is eigenvector i.  Emit the top r, largest first, as bf16 [r, l], and S = sqrt(max(w, 0)).
+// out_div / out_mul (optional): the same rows divided / multiplied by their singular value (a zero singular value gives a
+// zero row in out_div).
 __global__ void top_eigvecs_kernel(const float* __restrict__ vecs, const float* __restrict__ w, int l, int r,
-                                   bf16_t* __restrict__ out, float* __restrict__ S) {
+                                   bf16_t* __restrict__ out, float* __restrict__ S, bf16_t* __restrict__ out_div,
+                                   bf16_t* __restrict__ out_mul) {
     const int64_t bz = blockIdx.z;
     const int j = blockIdx.y;  // output row
     const int src = l - 1 - j;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < l) out[bz * l * l + (int64_t)j * l + c] = f32_to_bf16(vecs[bz * l * l + (int64_t)src * l + c]);
-    if (c == 0 && S) S[bz * r + j] = sqrtf(fmaxf(w[bz * l + src], 0.f));
+    const float sv = sqrtf(fmaxf(w[bz * l + src], 0.f));
+    if (c < l) {
+        const float v = vecs[bz * l * l + (int64_t)src * l + c];
+        const int64_t o = bz * l * l + (int64_t)j * l + c;
+        if (out) out[o] = f32_to_bf16(v);
+        if (out_div) out_div[o] = f32_to_bf16(sv > 0.f ? v / sv : 0.f);
+        if (out_mul) out_mul[o] = f32_to_bf16(v * sv);
+    }
+    if (c == 0 && S) S[bz * r + j] = sv;
+}
+
+// bf16 identity [batch][rows, l] and its transpose [batch][l, rows] (rows == l)
+__global__ void identity_pair_kernel(bf16_t* __restrict__ X, bf16_t* __restrict__ Xt, int l) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= l) return;
+    const int64_t o = (int64_t)blockIdx.z * l * l + (int64_t)i * l + j;
+    X[o] = Xt[o] = i == j ? (bf16_t)0x3f80 : (bf16_t)0;
 }
 
 // lora_left = bf16(bf16(L) / bf16(s[k])) row-wise (slim/lora.py:193-195)
@@ -274,6 +292,8 @@ struct FitWs {
     double* fro_part;  // [batch][FRO_BLOCKS] partial sums of squares
     float* slab;    // [batch][GRAM_MAX_SPLITS, l, l] split-K partials of the Gram products
     float* sketch_slab;  // [batch][SKETCH_MAX_SPLITS, l, max(N, K)] split-K partials of the sketch products
+    bf16_t* C16;    // [batch][Dm, Dm], Dm = min(N, K): the Gram matrix E^T E or E E^T of the Gram-side iteration
+    bf16_t* T16b;   // [batch][l, l] second set of scaled eigenvectors
     int* info;      // [batch][SLIM_FIT_INFO_WORDS]
     int* info_tmp;  // [batch] status words of one batched solver call
     int64_t total;
@@ -308,6 +328,8 @@ static FitWs fit_ws(char* base, int batch, int64_t N, int64_t K, int64_t l) {
     w.sketch_slab = (float*)take((int64_t)SKETCH_MAX_SPLITS * l * (N > K ? N : K) * 4);
     w.info = (int*)take(SLIM_FIT_INFO_WORDS * 4);
     w.info_tmp = (int*)take(4);
+    w.C16 = (bf16_t*)take((N < K ? N : K) * (N < K ? N : K) * 2);
+    w.T16b = (bf16_t*)take(l * l * 2);
     w.total = o;
     return w;
 }
@@ -632,6 +654,11 @@ extern "C" int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t r
 // FIT_BACK needs to resume.  FIT_BACK: from the eigenvectors (rows of ext_vecs, ascending, as slim_eigh_f32 leaves them),
 // eigenvalues ext_evals and solver status ext_info of M to the factors.  Front and back share the workspace.
 enum { FIT_ALL = 0, FIT_FRONT = 1, FIT_BACK = 2 };
+#define FIT_STATE_GRAM (1 << 30)      // marks a state word written by the Gram-side front half
+static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
+                         uint32_t seed, int flags, int cond_e, const float* s, void* U, void* Ut, void* L, float* S,
+                         int32_t* info_out, FitWs& w, void* stream, float* M_ext, int* state, const float* ext_vecs,
+                         const float* ext_evals, const int* ext_info);
 static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
                     uint32_t seed, int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S,
                     int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream, float* M_ext, int* state,
@@ -645,10 +672,16 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     SLIM_REQUIRE(2 * (n_iter + 1) + 1 <= SLIM_FIT_INFO_WORDS / 2, "slim_lowrank_fit: too many iterations");
     SLIM_REQUIRE(workspace_bytes >= slim_lowrank_fit_batched_workspace_bytes(batch, N, K, l), "slim_lowrank_fit: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    rb_handle h = nullptr;
-    CHK(solver_handle(st, &h));
     FitWs w = fit_ws((char*)workspace, batch, N, K, l);
     if (phase != FIT_BACK) SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    if (phase == FIT_BACK ? (*state & FIT_STATE_GRAM) != 0 : !(flags & (SLIM_FIT_TWO_SIDED | SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL))) {
+        int inner = state ? (*state & ~FIT_STATE_GRAM) : 0;
+        const int cond = ns_steps > 0 ? (ns_steps > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : ns_steps) : 9;
+        int rc = gram_fit_impl(phase, E, Et, batch, N, K, r, l, n_iter, seed, flags, cond, s, U, Ut, L, S, info_out, w, stream, M_ext,
+                               &inner, ext_vecs, ext_evals, ext_info);
+        if (rc == SLIM_OK && phase == FIT_FRONT) *state = inner | FIT_STATE_GRAM;
+        return rc;
+    }
     const bf16_t* Eb = (const bf16_t*)E;
     const bf16_t* Etb = (const bf16_t*)Et;
     const int64_t sE = N * K, sYn = N * l, sZk = K * l, sG = (int64_t)l * l;
@@ -720,6 +753,8 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
         CHK(slim_eigh_launch(w.G, l, batch, r, w.evals, w.info + ninfo, SLIM_FIT_INFO_WORDS, w.slab,
                              (int64_t)GRAM_MAX_SPLITS * l * l * 4 * batch, st));
     } else {
+        rb_handle h = nullptr;
+        CHK(solver_handle(st, &h));
         int syevd_tok = g_slim_prof_on ? slim_prof_begin("solver_syevd", st, 0.0, 9.0 * l * l * l * batch) : -1;
         if (batch > 1 && g_solver.syevd_sb) {
             if (g_solver.syevd_sb(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G, l, sG, w.evals, l, w.ework, l, w.info_tmp, batch) != 0) {
@@ -741,12 +776,134 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     {
         dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
         top_eigvecs_kernel<<<grid, 256, 0, st>>>(phase == FIT_BACK ? ext_vecs : w.G, phase == FIT_BACK ? ext_evals : w.evals, l, r,
-                                                 w.T16, S);
+                                                 w.T16, S, nullptr, nullptr);
         SLIM_LAUNCH_CHECK();
     }
     // L = V_r S_r = B^T W_r  [K, r];  U = Q W_r  [N, r] (+ U^T = lora_right)
     CHK(nt(batch, w.B[0].X, l, sZk, w.T16, l, sG, (int)K, r, l, nullptr, (bf16_t*)L, r, nullptr, 0, stream));
     CHK(nt(batch, w.A[a].X, l, sYn, w.T16, l, sG, (int)N, r, l, nullptr, (bf16_t*)U, r, (bf16_t*)Ut, N, stream));
+    if (s) CHK(scale_rows_batched(L, s, K, r, batch, stream));
+    if (info_out)
+        SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return SLIM_OK;
+}
+
+
+// ---- the fit by subspace iteration on the Gram matrix ------------------------------------------------------------------
+// With Dm = min(N, K) the small side of E, C = E^T E (K <= N) or E E^T (N < K) is formed once (a symmetric product: only
+// the tiles on and above the diagonal are computed) and the subspace iteration runs on C: one Dm x Dm x l product and one
+// orthonormalisation of a Dm x l iterate per iteration, against two products with the N x K matrix and two
+// orthonormalisations (one of them on the long side) for the alternating iteration above.  An application of C squares
+// the conditioning inside the subspace, so its orthonormalisation is sized for 2^(2 cond_e).  C is kept in bf16: its
+// rounding perturbs the eigenvectors by angles of the order 2^-9 x (entry size / eigenvalue gap), far below what the
+// 1e-3 budget of the reconstruction error notices (measured: identical excess with an fp32 C).  The Rayleigh-Ritz step
+// uses the matrix itself: Z = E P (or E^T P) for the orthonormal basis P of the right (left) subspace, M = Z^T Z.
+//   K <= N:  P [K, l] right basis;  Z = E P [N, l];  U = Z W S^-1,  L = P W S
+//   N <  K:  P [N, l] left basis;   Z = E^T P [K, l];  U = P W,     L = Z W
+static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, int64_t N, int64_t K, int r, int l, int n_iter,
+                         uint32_t seed, int flags, int cond_e, const float* s, void* U, void* Ut, void* L, float* S,
+                         int32_t* info_out, FitWs& w, void* stream, float* M_ext, int* state, const float* ext_vecs,
+                         const float* ext_evals, const int* ext_info) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool right = K <= N;
+    const int64_t Dm = right ? K : N, Dx = right ? N : K;
+    const bf16_t* Eb = (const bf16_t*)E;
+    const bf16_t* Etb = (const bf16_t*)Et;
+    const int64_t sE = N * K, sP = Dm * l, sZ = Dx * l, sG = (int64_t)l * l, sC = Dm * Dm;
+    const int64_t sSk = (int64_t)SKETCH_MAX_SPLITS * l * (N > K ? N : K);
+    float* sk_slab = (flags & SLIM_FIT_NO_SKETCH_SPLIT) ? nullptr : w.sketch_slab;
+    if (flags & SLIM_FIT_NO_SKETCH_SPLIT) w.gram_cap = GRAM_SPLITS_SHARED_CHIP;
+    Pair* Pb = right ? w.B : w.A;        // rotating buffers of the iterate (Dm rows)
+    Pair& Zb = right ? w.A[0] : w.B[0];  // the projection (Dx rows)
+    int ninfo = 0, a = 0;
+    if (phase != FIT_BACK) {
+        if (l == Dm) {
+            // the subspace is the whole space: any orthonormal basis will do, and the identity is exact
+            identity_pair_kernel<<<dim3((unsigned)((l + 255) / 256), (unsigned)l, (unsigned)batch), 256, 0, st>>>(Pb[0].X, Pb[0].Xt, l);
+            SLIM_LAUNCH_CHECK();
+            a = 0;
+        } else {
+            {   // C = E^T E (operand E^T [K, N]) or E E^T (operand E [N, K]), bf16, upper tiles mirrored
+                GemmArgs g;
+                g.A = g.B = right ? Etb : Eb;
+                g.lda = g.ldb = Dx;
+                g.M = g.N = (int)Dm;
+                g.Kd = (int)Dx;
+                g.C16 = g.Ct16 = w.C16;
+                g.ldc16 = g.ldct = Dm;
+                g.batch = batch;
+                g.sA = g.sB = sE;
+                g.sC16 = g.sCt = sC;
+                g.sym = 1;
+                CHK(slim_gemm_launch(g, stream));
+            }
+            const int e2 = 2 * cond_e > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : 2 * cond_e;
+            const int64_t n = (int64_t)l * Dm;
+            randn_bf16_kernel<<<dim3((unsigned)ceil_div64(n, 256), (unsigned)batch), 256, 0, st>>>(Pb[1].Xt, n, seed, sP);
+            SLIM_LAUNCH_CHECK();
+            int src = 1;
+            for (int it = 0; it <= n_iter; ++it) {
+                // Y^T = P^T C (C symmetric) -> Y^T [l, Dm] and Y [Dm, l] in the buffer after the source, then Q = orth(Y)
+                const int dst = (src + 1) % 3;
+                CHK(nt(batch, Pb[src].Xt, Dm, sP, w.C16, Dm, sC, l, (int)Dm, (int)Dm, nullptr, Pb[dst].Xt, Dm, Pb[dst].X, l, stream,
+                       sk_slab, sSk));
+                CHK(orth(Pb, dst, Dm, l, it == n_iter, flags, e2, w, ninfo, stream, &a));
+                ninfo += 2;
+                src = a;
+            }
+        }
+        // Z^T = P^T E^T (operand E [N, K]: Z = E P) or P^T E (operand E^T: Z = E^T P) -> Z^T [l, Dx] and Z [Dx, l]
+        CHK(nt(batch, Pb[a].Xt, Dm, sP, right ? Eb : Etb, Dm, sE, l, (int)Dx, (int)Dm, nullptr, Zb.Xt, Dx, Zb.X, l, stream, sk_slab, sSk));
+        CHK(gram(Zb.Xt, Dx, l, w, nullptr, stream));
+        if (phase == FIT_FRONT) {
+            SLIM_REQUIRE(M_ext && state, "slim_lowrank_fit_front: bad arguments");
+            SLIM_HIP(hipMemcpyAsync(M_ext, w.G, (size_t)batch * sG * sizeof(float), hipMemcpyDeviceToDevice, st));
+            *state = a | (ninfo << 8);
+            return SLIM_OK;
+        }
+    } else {
+        SLIM_REQUIRE(state && ext_vecs && ext_evals, "slim_lowrank_fit_back: bad arguments");
+        a = *state & 0xff;
+        ninfo = *state >> 8;
+        SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS, "slim_lowrank_fit_back: bad state");
+        if (ext_info) {
+            info_scatter_kernel<<<(batch + 63) / 64, 64, 0, st>>>(ext_info, batch, w.info, ninfo);
+            SLIM_LAUNCH_CHECK();
+        }
+    }
+    if (phase == FIT_ALL) {
+        if (!(flags & SLIM_FIT_LIBRARY_EIGH) && slim_eigh_supported(l) &&
+            slim_eigh_ws_bytes(l, batch) <= (int64_t)GRAM_MAX_SPLITS * l * l * 4 * batch) {
+            CHK(slim_eigh_launch(w.G, l, batch, r, w.evals, w.info + ninfo, SLIM_FIT_INFO_WORDS, w.slab,
+                                 (int64_t)GRAM_MAX_SPLITS * l * l * 4 * batch, st));
+        } else {
+            rb_handle h = nullptr;
+            CHK(solver_handle(st, &h));
+            for (int bi = 0; bi < batch; ++bi)
+                if (g_solver.syevd(h, RB_EVECT_ORIGINAL, RB_FILL_UPPER, l, w.G + bi * sG, l, w.evals + (int64_t)bi * l,
+                                   w.ework + (int64_t)bi * l, w.info + bi * SLIM_FIT_INFO_WORDS + ninfo) != 0) {
+                    slim_set_error("rocsolver_ssyevd failed");
+                    return SLIM_ERR_SOLVER;
+                }
+        }
+    }
+    ninfo += 1;
+    const float* vecs = phase == FIT_BACK ? ext_vecs : w.G;
+    const float* evals = phase == FIT_BACK ? ext_evals : w.evals;
+    const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
+    if (right) {
+        // U = Z (W S^-1), L = P (W S)
+        top_eigvecs_kernel<<<grid, 256, 0, st>>>(vecs, evals, l, r, nullptr, S, w.T16, w.T16b);
+        SLIM_LAUNCH_CHECK();
+        CHK(nt(batch, Pb[a].X, l, sP, w.T16b, l, sG, (int)K, r, l, nullptr, (bf16_t*)L, r, nullptr, 0, stream));
+        CHK(nt(batch, Zb.X, l, sZ, w.T16, l, sG, (int)N, r, l, nullptr, (bf16_t*)U, r, (bf16_t*)Ut, N, stream));
+    } else {
+        // U = P W, L = Z W
+        top_eigvecs_kernel<<<grid, 256, 0, st>>>(vecs, evals, l, r, w.T16, S, nullptr, nullptr);
+        SLIM_LAUNCH_CHECK();
+        CHK(nt(batch, Zb.X, l, sZ, w.T16, l, sG, (int)K, r, l, nullptr, (bf16_t*)L, r, nullptr, 0, stream));
+        CHK(nt(batch, Pb[a].X, l, sP, w.T16, l, sG, (int)N, r, l, nullptr, (bf16_t*)U, r, (bf16_t*)Ut, N, stream));
+    }
     if (s) CHK(scale_rows_batched(L, s, K, r, batch, stream));
     if (info_out)
         SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
