@@ -24,6 +24,11 @@ extern "C" {
 
 #define SLIM_HIP_ABI_VERSION 1
 #define SLIM_FIT_INFO_WORDS 64
+/* info_out of the fits: words 0 .. 62 are status words of solver / orthonormalisation steps (0 = fine).  Word 63 is not
+ * an error: 0, or -- when the singular values of E inside the fitted subspace turned out to be spread over more than the
+ * 2^ns_steps the orthonormalisations were sized for -- the ns_steps value that covers them; the fit should then be
+ * repeated with it (its result may have lost accuracy in the weakest directions). */
+#define SLIM_FIT_INFO_COND_WORD 63
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_TWO_SIDED 2    /* alternating subspace iteration on E and E^T (two products with the N x K matrix and two
                                  * orthonormalisations per iteration) instead of the iteration on the Gram matrix of E */

@@ -18,6 +18,8 @@
 #include "eigh.hpp"
 #include <dlfcn.h>
 
+#define NS_SCHED_MAX_E 12      // widest Newton-Schulz schedule: singular values within a factor 2^12
+
 // ---- rocSOLVER / rocBLAS entry points, resolved at first use ---------------------------------
 Solver g_solver;
 
@@ -141,6 +143,28 @@ __global__ void top_eigvecs_kernel(const float* __restrict__ vecs, const float* 
     if (c == 0 && S) S[bz * r + j] = sv;
 }
 
+// After the fit: the eigenvalues of the Rayleigh-Ritz matrix are the squared singular values of E inside the subspace, so
+// their extreme ratio is the conditioning the orthonormalisations had to cope with.  When it exceeds what they were sized
+// for (2^cond_e, half a level of slack), the last status word of the problem receives the level that would have covered it
+// and the caller fits that layer again; otherwise 0.  (An application of the Gram matrix squares the conditioning, which
+// the fit allows for by itself: cond_e and the level reported are in terms of the singular values of E.)
+__global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r, int batch, int cond_e, int* __restrict__ info) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    // ascending eigenvalues; the weakest direction that still matters sits halfway into the oversampling part
+    const float hi = evals[(int64_t)b * l + l - 1], lo = evals[(int64_t)b * l + (l - r) / 2];
+    int need = 0;
+    if (hi > 0.f) {
+        const float lg = lo > 0.f ? 0.5f * log2f(hi / lo) : 100.f;
+        if (lg > (float)cond_e + 0.5f) {
+            need = (int)ceilf(lg);
+            if (need > NS_SCHED_MAX_E / 2) need = NS_SCHED_MAX_E / 2;
+            if (need <= cond_e) need = 0;      // already at the widest schedule
+        }
+    }
+    info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_WORDS - 1] = need;
+}
+
 // bf16 identity [batch][rows, l] and its transpose [batch][l, rows] (rows == l)
 __global__ void identity_pair_kernel(bf16_t* __restrict__ X, bf16_t* __restrict__ Xt, int l) {
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,7 +267,6 @@ __global__ void shifted_gram_bf16_kernel(const float* __restrict__ G, const floa
 // (tools/ns_schedule.py: linear programme on a grid, each interval widened by 5 % at the top for the rounding of bf16
 // iterates and polynomials, positivity checked on [0, 1.05]): `enough` steps leave a conditioning of at most 2.35 -- all an intermediate
 // basis of the subspace iteration needs -- and all `total` steps leave the singular values within 0.5 % of 1.
-#define NS_SCHED_MAX_E 12
 #define NS_SCHED_MAX_STEPS 7
 struct NsStep {
     float a, b, c;
@@ -858,14 +881,15 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
         if (phase == FIT_FRONT) {
             SLIM_REQUIRE(M_ext && state, "slim_lowrank_fit_front: bad arguments");
             SLIM_HIP(hipMemcpyAsync(M_ext, w.G, (size_t)batch * sG * sizeof(float), hipMemcpyDeviceToDevice, st));
-            *state = a | (ninfo << 8);
+            *state = a | (ninfo << 8) | (cond_e << 16);
             return SLIM_OK;
         }
     } else {
         SLIM_REQUIRE(state && ext_vecs && ext_evals, "slim_lowrank_fit_back: bad arguments");
         a = *state & 0xff;
-        ninfo = *state >> 8;
-        SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS, "slim_lowrank_fit_back: bad state");
+        ninfo = (*state >> 8) & 0xff;
+        cond_e = (*state >> 16) & 0xff;
+        SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS - 1, "slim_lowrank_fit_back: bad state");
         if (ext_info) {
             info_scatter_kernel<<<(batch + 63) / 64, 64, 0, st>>>(ext_info, batch, w.info, ninfo);
             SLIM_LAUNCH_CHECK();
@@ -890,6 +914,10 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
     ninfo += 1;
     const float* vecs = phase == FIT_BACK ? ext_vecs : w.G;
     const float* evals = phase == FIT_BACK ? ext_evals : w.evals;
+    if (l < Dm) {
+        cond_check_kernel<<<(batch + 63) / 64, 64, 0, st>>>(evals, l, r, batch, cond_e, w.info);
+        SLIM_LAUNCH_CHECK();
+    }
     const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
     if (right) {
         // U = Z (W S^-1), L = P (W S)

@@ -35,9 +35,17 @@ def fit_ns_steps(spread):
     slim_lowrank_fit), from the spread max(s) / median(s) of the saliency scales that are left after the outlier columns
     have been split off.  The error matrix is (benign matrix) x diag(s): its largest singular values come from the columns
     with the largest scale, the bulk from the typical ones, so the conditioning of an iterate inside the leading subspace
-    is of the order of the spread (measured: about a third of it)."""
+    is of the order of the spread (measured: about a third of it, so half the spread is assumed).  The fit checks the
+    assumption against the spectrum it finds (status word SLIM_FIT_INFO_COND_WORD) and the driver repeats a fit whose
+    estimate was too low with FIT_COND_FLOOR raised (prune.compress_linears)."""
     import math
-    return int(min(12, max(2, math.ceil(math.log2(max(float(spread), 1.0))))))
+    if os.environ.get("SLIM_FIT_COND_E"):          # tuning aid: fixed value
+        return int(os.environ["SLIM_FIT_COND_E"])
+    return int(min(6, max(1, FIT_COND_FLOOR, math.ceil(math.log2(max(float(spread) / 2.0, 1.0))))))
+
+
+# lower bound of fit_ns_steps; raised by the driver while it repeats fits whose conditioning was underestimated
+FIT_COND_FLOOR = 0
 
 
 # Columns of the error matrix whose saliency scale exceeds OUTLIER_RATIO x the median are split off and
@@ -274,6 +282,10 @@ def _outliers_from_host(top_vals, median, top_idx, rank=None):
     t_pad = min(_round_up8(t), (len(top_vals) - 1) // 8 * 8)
     t = min(t, t_pad)
     rest = top_vals[t] / median if t < len(top_vals) else 1.0
+    # a split-off column leaves behind what the bf16 rounding of its exact part could not hold, about 2^-8 of it: for
+    # scales thousands of times the median that remainder is itself an outlier column of the matrix the fit sees
+    if t:
+        rest = max(rest, top_vals[0] / median / 256.0)
     return ((top_idx[:t_pad].contiguous(), t) if t else None), max(rest, 1.0)
 
 

@@ -245,25 +245,60 @@ def _run_block(layer, src, dst, kwargs, batch):
             dst[j:j + batch] = out
 
 
+COND_WORD = 63        # SLIM_FIT_INFO_COND_WORD of the last 64-word status block of a fit
+
+
 def check_fit_status(items):
     """Raise if the low-rank fit of any of these linears reported a failure (a status word of its eigen-solver or of an
     orthonormalisation is non-zero): such a fit leaves arbitrary adapters and a residual weight quantised against them.
-    One host synchronisation for the whole block."""
-    named = [(name, lin.lora_fit_info) for name, lin, _ in items if getattr(lin, "lora_fit_info", None) is not None]
+    Returns {index in items: level} for the fits that ask to be repeated with orthonormalisations sized for a wider
+    spread of singular values (their last status word).  One host synchronisation for the whole block."""
+    named = [(i, name, lin.lora_fit_info) for i, (name, lin, _) in enumerate(items)
+             if getattr(lin, "lora_fit_info", None) is not None]
     if not named:
-        return
-    bad = torch.stack([info.ne(0).any() for _, info in named]).cpu().tolist()
-    failed = [(name, info.cpu().tolist()) for (name, info), b in zip(named, bad) if b]
+        return {}
+    flags = torch.stack([torch.stack([info[:-1].ne(0).any().to(torch.int32), info[-1].to(torch.int32)])
+                         for _, _, info in named]).cpu().tolist()
+    failed = [(name, info[:-1].cpu().tolist()) for (_, name, info), f in zip(named, flags) if f[0]]
     if failed:
         from ._lib import SlimHipError, ERR_SOLVER
         raise SlimHipError("low-rank fit", ERR_SOLVER, "; ".join(
             f"{name}: status words {[w for w in words if w][:8]}" for name, words in failed))
+    return {i: int(f[1]) for (i, _, _), f in zip(named, flags) if f[1] > 0}
+
+
+def _reset_linear(lin, weight):
+    """Undo what compress_linears left on a linear (for a repeated fit): original weight, no adapters, no adapter hook."""
+    lin.weight.data = weight
+    for attr in ("lora_left", "lora_right", "lora_rank", "scaling_factor", "lora_fit_info", "lora_left_mask"):
+        if hasattr(lin, attr):
+            delattr(lin, attr)
+    for key in [k for k, h in lin._forward_hooks.items() if h is add_lora_hook]:
+        del lin._forward_hooks[key]
 
 
 def compress_linears(items, dev, *args, **kwargs):
-    """compress_linears_unchecked + check_fit_status (the driver's entry)."""
+    """compress_linears_unchecked, then the status words of the fits (one host synchronisation per block): failures
+    raise; fits whose orthonormalisations turned out to be sized for too narrow a spectrum are repeated once with the
+    level they report."""
+    from . import lora as _lora
+    originals = [lin.weight.data for _, lin, _ in items]
+    masks = [getattr(lin.weight, "mask", None) for _, lin, _ in items]
     compress_linears_unchecked(items, dev, *args, **kwargs)
-    check_fit_status(items)
+    again = check_fit_status(items)
+    if not again:
+        return
+    for i in again:
+        _reset_linear(items[i][1], originals[i])
+        if masks[i] is not None:
+            items[i][1].weight.mask = masks[i]
+    floor = _lora.FIT_COND_FLOOR
+    _lora.FIT_COND_FLOOR = max(again.values())
+    try:
+        compress_linears_unchecked([items[i] for i in sorted(again)], dev, *args, **kwargs)
+    finally:
+        _lora.FIT_COND_FLOOR = floor
+    check_fit_status([items[i] for i in sorted(again)])       # failures still raise; a second request is not followed
 
 
 def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,

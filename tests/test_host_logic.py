@@ -150,6 +150,11 @@ def test_failed_fit_status_is_raised():
     ok.lora_fit_info = torch.zeros(64, dtype=torch.int32)
     bad.lora_fit_info = torch.zeros(64, dtype=torch.int32)
     bad.lora_fit_info[5] = 3
-    check_fit_status([("q_proj", ok, None), ("no_fit", Lin(), None)])
+    assert check_fit_status([("q_proj", ok, None), ("no_fit", Lin(), None)]) == {}
     with pytest.raises(SlimHipError, match="k_proj"):
         check_fit_status([("q_proj", ok, None), ("k_proj", bad, None)])
+    # the last word is a request to repeat the fit with wider orthonormalisations, not a failure
+    wide = Lin()
+    wide.lora_fit_info = torch.zeros(128, dtype=torch.int32)
+    wide.lora_fit_info[-1] = 4
+    assert check_fit_status([("q_proj", ok, None), ("v_proj", wide, None)]) == {1: 4}
