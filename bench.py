@@ -5,7 +5,7 @@
 One step = the per-layer compression hot path over one decoder block: for each of its 7 linears
 (q/k/v/o 4096x4096, gate/up 11008x4096, down 4096x11008): calibration statistics from 128 x 2048
 synthetic bf16 activations -> shift_zeros -> saliency + 2:4 mask -> scale search + quantise -> error
-matrix -> rank-512 low-rank fit -> residual -> second scale search + re-quantisation.
+matrix -> rank-512 low-rank fit -> residual -> second scale search + re-quantisation -> 2:4 4-bit packing.
 Metric: weight GB/s compressed = sum(2 N K bytes of the linears compressed) / wall-clock.
 
 N GPUs: the 7 independent linears of the block are partitioned over the ranks by cost (longest
@@ -64,38 +64,47 @@ def collect_stats(lin, X):
     return wrapped
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The CPU oracle (torch-CPU restatement of the reference algorithm) on a bounded sample of the same
-    workload: one 4096 x 4096 linear of the block with 4 of the 128 calibration samples."""
+def cpu_baseline():
+    """The CPU oracle (torch-CPU restatement of the reference algorithm: per-sample statistics, per-group topk mask,
+    torch.histogram + candidate loop twice, full torch.svd, re-quantisation) on a bounded sample of the same workload: one
+    linear of each of the block's three distinct shapes, statistics over 4 of the 128 calibration samples."""
     from oracle import slim_oracle as O
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
-    N = K = 4096
-    W = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
-    X = (torch.randn(4, 2048, K, generator=g) * torch.exp(torch.randn(K, generator=g) * 0.5)).to(torch.bfloat16)
-    t0 = time.time()
-    sr, n = torch.zeros(K), 0
-    for j in range(4):
-        sr, n = O.add_batch_scaler_row(sr, n, X[j])
-    O.compress_linear(W, sr, rank_ratio=0.1, num_bits=4, tile=256)
-    dt = time.time() - t0
-    return {"value": 2.0 * N * K / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"one 4096x4096 linear of the block (stats over 4 of 128 samples, mask, 2 scale searches, "
-                      f"full torch.svd, re-quantisation): {dt:.1f} s", "seconds": dt}
+    times, nbytes = {}, 0.0
+    for name, N, K in (("4096x4096", 4096, 4096), ("11008x4096", 11008, 4096), ("4096x11008", 4096, 11008)):
+        W = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+        X = (torch.randn(4, 2048, K, generator=g) * torch.exp(torch.randn(K, generator=g) * 0.5)).to(torch.bfloat16)
+        t0 = time.time()
+        sr, n = torch.zeros(K), 0
+        for j in range(4):
+            sr, n = O.add_batch_scaler_row(sr, n, X[j])
+        O.compress_linear(W, sr, rank_ratio=0.1, num_bits=4, tile=256)
+        times[name] = time.time() - t0
+        nbytes += 2.0 * N * K
+    dt = sum(times.values())
+    block_s = 4 * times["4096x4096"] + 2 * times["11008x4096"] + times["4096x11008"]
+    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": "one linear of each distinct shape of the block (4096x4096, 11008x4096, 4096x11008), statistics over 4 of "
+                      "128 samples, mask, 2 scale searches, full torch.svd, re-quantisation: "
+                      + ", ".join(f"{k} {v:.1f} s" for k, v in times.items()),
+            "seconds": dt, "block_of_7_linears_extrapolated_s": block_s}
 
 
 # kernel symbol (as a profiler prints it) of each family the in-library timer reports
 FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0,", "gemm_nt_small": "gemm_nt_kernel<1,", "gemm_nt_apply": "gemm_nt_kernel<2,",
                  "gemm_nt_sketch": "gemm_nt_kernel<3,", "gemm_nt_big": "gemm_nt_kernel<4,", "gemm_nt_residual": "gemm_nt_kernel<5,",
-                 "eigh_tridiag": "tridiag_step_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
+                 "eigh_tridiag": "tridiag_step_kernel", "eigh_multisect": "tri_multisect_kernel", "eigh_twisted": "tri_twisted_kernel",
+                 "gemm_f32": "f32_gemm_kernel", "pack24": "pack24_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
                  "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel"}
 
 
 def measured_traffic(family):
     """HBM bytes per launch of a kernel family from the committed PMC measurement of this same command
-    (profiles/r1e_pmc_traffic.json, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1e_pmc_traffic.json")
+    (profiles/r2_pmc_traffic.json, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs of
+    `bench.py --streams 1 --steps 1 --warmup 1 --no-e2e --no-cpu-baseline`), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
     sym = FAMILY_KERNEL.get(family)
     if sym is None or not os.path.exists(path):
         return None
@@ -117,6 +126,8 @@ def main():
     ap.add_argument("--nsamples", type=int, default=128)
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the measured end-to-end compression of the whole LLaMA-2-7B-shaped "
+                                                         "model (slim.prune.prune_and_quantize, ~15 s) after the timed steps")
     ap.add_argument("--streams", type=int, default=7, help="HIP streams the linears of a block are spread over")
     ap.add_argument("--rehearse-backend", default=None,
                     help="rehearsal of the multi-rank path on fewer GPUs than ranks: process-group backend (gloo); ranks "
@@ -173,6 +184,8 @@ def main():
     from slim_amd.layerwrapper import shared_inputs
     from slim_amd.quantization.quantization import Quantizer
 
+    packed = {}
+
     def step(n_streams=None):
         wrapped = {}
         # statistics pass (in the driver: hooks of the block forward).  As in a decoder block, q/k/v and gate/up
@@ -190,6 +203,10 @@ def main():
         compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in mine], dev, 2, 4,
                          sparsity_ratio=0.5, quantizer=Quantizer("weight", num_bits=4, slim_quant=True), lora_rank=0.1, slim_lora=True,
                          quantize_lora=True, lora_tile_size=256, n_streams=args.streams if n_streams is None else n_streams)
+        # pack: the compressed weight in its 2:4 4-bit storage form (0.375 byte per element); the status words are read
+        # after the timed region
+        for i in mine:
+            packed[i] = ops.pack24(lins[i].weight.data, lins[i].scaling_factor, check=False)
         if world > 1:
             # exchange step: every rank receives the compressed shards of the linears it does not own
             for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK):
@@ -219,6 +236,8 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    for i in mine:
+        ops.pack24_raise(int(packed[i][2].item()))
     # The same steps once more with the in-library timer on (a HIP-event pair around every launch, on the launch's own
     # stream): the per-family table.  Kept out of the timed region above because the event packets themselves cost
     # dispatch slots on a step made of thousands of short launches; the instrumented time is reported beside it.
@@ -281,9 +300,9 @@ def main():
             return out
         rows = table(prof, f"per-family timing over {args.steps} instrumented steps, {args.streams} streams (rank 0)")
         rows_single = table(prof_single, "per-family timing of one extra step on a single stream") if prof_single else rows
-        # the dominant KERNEL among the library's own (rocSOLVER / rocBLAS scopes are not its kernels); the
-        # tridiagonalisation scope counts its one-launch-per-column chain per launch
-        own = [r for r in rows_single if not r["name"].startswith(("solver_", "eigh_backproduct"))]
+        # the dominant kernel family by GPU time, whatever it is (a scope that counts a chain of identical launches, like
+        # the tridiagonalisation's one launch per column, is reported per launch)
+        own = list(rows_single)
         def roof(dom):
             if dom is None:
                 return None
@@ -310,7 +329,7 @@ def main():
                                    "SLiM-Quant 4-bit + lora_rank 0.1 (r=512, tile 256), "
                                    f"{args.nsamples}x{args.seqlen} synthetic calibration activations resident in HBM",
                        "partition": f"layer-level over {world} rank(s)" + (" + RCCL broadcast of shards" if world > 1 else ""),
-                       "wallclock_7b_extrapolated_s": ms_per_step * 32 / 1e3,
+                       "compression_only_extrapolated_s": ms_per_step * 32 / 1e3,
                        "ms_per_step_with_event_timers": dt_instrumented / args.steps * 1e3},
             "roofline": roofline,
             "roofline_top_gemm": roofline_gemm,
@@ -320,6 +339,21 @@ def main():
                                                   "avg_us": round(r["avg_us"], 2), "GBps": round(r["gbs"], 1),
                                                   "TFLOPps": round(r["tfs"], 2)} for r in rows_single},
         }
+        if world == 1 and not args.no_e2e and not args.only:
+            # the second half of the metric, measured: slim.prune.prune_and_quantize on a random-init LLaMA-2-7B-shaped
+            # model (32 blocks, 224 linears, 12.95 GB of linear weights), 128 x 2048 synthetic calibration tokens,
+            # including the model's own two forward passes per block that the kernel benchmark above leaves out
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from e2e_compress import run_e2e
+            for t in list(lins.values()) + list(acts.values()) + list(W0.values()):
+                del t
+            lins.clear(), acts.clear(), W0.clear(), packed.clear()
+            torch.cuda.empty_cache()
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # the dispatcher prints what it does, as the reference's does
+                e2e = run_e2e("llama2-7b", nsamples=args.nsamples, seqlen=args.seqlen, streams=args.streams)
+            out["config"]["wallclock_7b_measured_s"] = e2e["compress_wallclock_s"]
+            out["config"]["wallclock_7b_measured"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

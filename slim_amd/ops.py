@@ -577,9 +577,10 @@ def packed24_bytes(N, K):
     return v.value, m.value
 
 
-def pack24(W, sf):
+def pack24(W, sf, check=True):
     """(vals uint8, meta uint8) packed form of a 2:4-sparse 4-bit weight W = bf16(c / sf).  Synchronises once to
-    read the status word; raises ValueError when W is not of that form."""
+    read the status word and raises ValueError when W is not of that form; check=False returns (vals, meta, status)
+    without synchronising (status: int32 device tensor, see pack24_raise)."""
     W = _chk(W, BF16, "W")
     sf = _chk(sf, torch.float32, "sf").reshape(-1)[:1]
     N, K = W.shape
@@ -588,12 +589,18 @@ def pack24(W, sf):
     meta = torch.empty(mb, dtype=torch.uint8, device=W.device)
     status = torch.empty(1, dtype=torch.int32, device=W.device)
     _lib.call("slim_pack24_int4", _p(W), _p(sf), N, K, _p(vals), _p(meta), _p(status), _stream())
-    st = int(status.item())
+    if not check:
+        return vals, meta, status
+    pack24_raise(int(status.item()))
+    return vals, meta
+
+
+def pack24_raise(st):
+    """Raise for a non-zero status word of pack24."""
     if st & 1:
         raise ValueError("pack24: the weight is not 2:4 sparse (a group of 4 input channels holds more than two non-zeros)")
     if st & 2:
         raise ValueError("pack24: the weight holds values that are not 4-bit quantisation levels of the given scaling factor")
-    return vals, meta
 
 
 def unpack24(vals, meta, sf, N, K):

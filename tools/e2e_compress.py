@@ -23,6 +23,12 @@ SHAPES = {
 }
 
 
+def run_e2e(model="llama2-7b", layers=0, nsamples=128, seqlen=2048, calib_batch=8, streams=7, pack=False, ppl=False):
+    """prune_and_quantize (the drop-in entry) on a random-init model of the given shape; returns the record main() prints."""
+    return _run(argparse.Namespace(model=model, layers=layers, nsamples=nsamples, seqlen=seqlen, calib_batch=calib_batch,
+                                   streams=streams, pack=pack, ppl=ppl))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama2-7b", choices=sorted(SHAPES))
@@ -34,7 +40,10 @@ def main():
     ap.add_argument("--pack", action="store_true", help="afterwards replace the linears by PackedLinear and report sizes / decode latency")
     ap.add_argument("--ppl", action="store_true", help="also evaluate synthetic-token perplexity before/after")
     args = ap.parse_args()
+    print(json.dumps(_run(args)))
 
+
+def _run(args):
     from transformers import LlamaConfig, LlamaForCausalLM
     import slim.prune as P
     from slim.eval import eval_ppl_wikitext
@@ -56,6 +65,7 @@ def main():
     torch.cuda.synchronize()
     t_build = time.time() - t0
     calib, test = get_synthetic(args.nsamples, 0, args.seqlen, cfg["vocab_size"])
+    saved = (P.get_loaders, P.CALIBRATION_BATCH, P.KEEP_ON_DEVICE, P.COMPRESS_STREAMS)
     P.get_loaders = lambda *a, **k: (calib, None)
     P.CALIBRATION_BATCH = args.calib_batch
     P.KEEP_ON_DEVICE = True
@@ -73,6 +83,7 @@ def main():
                          slim_lora=True, quantize_lora=True, lora_tile_size=256)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    P.get_loaders, P.CALIBRATION_BATCH, P.KEEP_ON_DEVICE, P.COMPRESS_STREAMS = saved
     out.update(compress_wallclock_s=round(dt, 2), weight_GBps=round(nbytes / 1e9 / dt, 3),
                peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     if args.ppl:
@@ -103,7 +114,7 @@ def main():
                    packed_logits_max_abs_diff=round((got.float() - ref.float()).abs().max().item(), 4))
         if args.ppl:
             out["ppl_packed_fp32loss"] = eval_ppl_wikitext(model, test, 1, dev, fp32_loss=True)
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

@@ -28,8 +28,9 @@ def load(path, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    known = float(sys.argv[4])
     cal_name = next(k for k in fetch if "colsumsq_kernel" in k)
+    # "<bytes>/launch": the average bytes per launch of the calibration kernel instead of the run's total
+    known = float(sys.argv[4][:-7]) * fetch[cal_name][0] if sys.argv[4].endswith("/launch") else float(sys.argv[4])
     read_unit = known / fetch[cal_name][1]
     out = {"calibration": {"kernel": cal_name, "known_bytes_total": known, "counter_total": fetch[cal_name][1],
                            "bytes_per_fetch_unit": read_unit, "bytes_per_write_unit": 1024.0}, "kernels": {}}
