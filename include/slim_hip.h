@@ -281,6 +281,27 @@ int slim_lowrank_fit_back_batched(int batch, int64_t N, int64_t K, int r, int l,
                                   void* Ut, void* L, float* S, int32_t* info_out, void* workspace, int64_t workspace_bytes,
                                   void* stream);
 
+/* The pieces of the fit for a layer that several GPUs hold in shards along its long dimension (no counterpart in the
+ * reference, which is single-GPU; what they compute is part of the torch.svd of slim/lora.py:172).  With Dm the short
+ * dimension of E: (1) every GPU forms the Dm x Dm Gram matrix of its shard (slim_gemm_nt_bf16, fp32 output) and the
+ * shards' sum goes to one GPU; (2) slim_gramfit_iterate: subspace iteration on that matrix (bf16 [Dm, Dm]) -> orthonormal
+ * basis P [Dm, l] and P^T; (3) slim_gramfit_project: Z = X P [rows, l] (+ Z^T) for the shard X [rows, Dm] of E or E^T, and
+ * the shard's share M32 [l, l] = Z^T Z of the Rayleigh-Ritz matrix; (4) after the eigenproblem of the summed M
+ * (slim_tridiagonalize_f32 + slim_eigh_tail_f32), slim_gramfit_factors: right != 0 (Dm = K): dm_out = lora_left = P W S
+ * [K, r], rows_out = this shard's rows of U = Z W S^-1; right == 0 (Dm = N): dm_out = U = P W [N, r], rows_out = this
+ * shard's rows of lora_left = Z W.  s: saliency scales of lora_left's rows (it is divided by bf16(s)); the transposed
+ * outputs are optional.  info (optional, the 64 status words of slim_gramfit_iterate): word SLIM_FIT_INFO_COND_WORD receives
+ * the conditioning check for an iteration sized for cond_e, as in slim_lowrank_fit.  Workspaces:
+ * slim_gramfit_workspace_bytes(Dm or rows, l); factors: 2 * (l * l * 2 rounded up to 256). */
+int64_t slim_gramfit_workspace_bytes(int64_t rows, int64_t l);
+int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_iter, uint32_t seed, int flags, int cond_e, void* P, void* Pt,
+                         int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream);
+int slim_gramfit_project(const void* X, int64_t rows, int64_t Dm, int l, const void* Pt, void* Z, void* Zt, float* M32,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+int slim_gramfit_factors(int right, const void* P, const void* Z, int64_t Dm, int64_t rows, int l, int r, const float* vecs,
+                         const float* evals, const float* s, void* dm_out, void* dm_out_t, void* rows_out, void* rows_out_t,
+                         float* S, int cond_e, int32_t* info, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* slim/lora.py:199-201: Wn = mask ? 0 : bf16(W - bf16(U L^T)); U [N, r], L [K, r].  LR_bf16 (the
  * N x K low-rank product itself) is written too when non-NULL; mask may be NULL (nothing zeroed). */
 int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W_bf16,

@@ -813,6 +813,33 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
 
 
 // ---- the fit by subspace iteration on the Gram matrix ------------------------------------------------------------------
+// Subspace iteration on the symmetric matrix C [batch][Dm, Dm] (bf16): n_iter + 1 applications of C to an l-column
+// iterate that starts as a Gaussian matrix, each followed by an orthonormalisation (the last one to the accuracy of a
+// final basis).  Pb: three rotating buffer pairs of Dm rows; *a_out = index of the pair that holds the basis P.
+static int gram_iterate(Pair* Pb, const bf16_t* C16, int64_t sC, int batch, int64_t Dm, int l, int n_iter, uint32_t seed,
+                        int flags, int cond_e, FitWs& w, float* sk_slab, int64_t sSk, void* stream, int* a_out, int* ninfo) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t sP = Dm * l;
+    // an application of C squares the conditioning inside the subspace
+    const int e2 = 2 * cond_e > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : 2 * cond_e;
+    const int64_t n = (int64_t)l * Dm;
+    randn_bf16_kernel<<<dim3((unsigned)ceil_div64(n, 256), (unsigned)batch), 256, 0, st>>>(Pb[1].Xt, n, seed, sP);
+    SLIM_LAUNCH_CHECK();
+    int src = 1, a = 1;
+    for (int it = 0; it <= n_iter; ++it) {
+        // Y^T = P^T C (C symmetric) -> Y^T [l, Dm] and Y [Dm, l] in the buffer after the source, then Q = orth(Y)
+        const int dst = (src + 1) % 3;
+        CHK(nt(batch, Pb[src].Xt, Dm, sP, C16, Dm, sC, l, (int)Dm, (int)Dm, nullptr, Pb[dst].Xt, Dm, Pb[dst].X, l, stream, sk_slab,
+               sSk));
+        CHK(orth(Pb, dst, Dm, l, it == n_iter, flags, e2, w, *ninfo, stream, &a));
+        *ninfo += 2;
+        src = a;
+    }
+    *a_out = a;
+    return SLIM_OK;
+}
+
+
 // With Dm = min(N, K) the small side of E, C = E^T E (K <= N) or E E^T (N < K) is formed once (a symmetric product: only
 // the tiles on and above the diagonal are computed) and the subspace iteration runs on C: one Dm x Dm x l product and one
 // orthonormalisation of a Dm x l iterate per iteration, against two products with the N x K matrix and two
@@ -860,20 +887,7 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
                 g.sym = 1;
                 CHK(slim_gemm_launch(g, stream));
             }
-            const int e2 = 2 * cond_e > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : 2 * cond_e;
-            const int64_t n = (int64_t)l * Dm;
-            randn_bf16_kernel<<<dim3((unsigned)ceil_div64(n, 256), (unsigned)batch), 256, 0, st>>>(Pb[1].Xt, n, seed, sP);
-            SLIM_LAUNCH_CHECK();
-            int src = 1;
-            for (int it = 0; it <= n_iter; ++it) {
-                // Y^T = P^T C (C symmetric) -> Y^T [l, Dm] and Y [Dm, l] in the buffer after the source, then Q = orth(Y)
-                const int dst = (src + 1) % 3;
-                CHK(nt(batch, Pb[src].Xt, Dm, sP, w.C16, Dm, sC, l, (int)Dm, (int)Dm, nullptr, Pb[dst].Xt, Dm, Pb[dst].X, l, stream,
-                       sk_slab, sSk));
-                CHK(orth(Pb, dst, Dm, l, it == n_iter, flags, e2, w, ninfo, stream, &a));
-                ninfo += 2;
-                src = a;
-            }
+            CHK(gram_iterate(Pb, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond_e, w, sk_slab, sSk, stream, &a, &ninfo));
         }
         // Z^T = P^T E^T (operand E [N, K]: Z = E P) or P^T E (operand E^T: Z = E^T P) -> Z^T [l, Dx] and Z [Dx, l]
         CHK(nt(batch, Pb[a].Xt, Dm, sP, right ? Eb : Etb, Dm, sE, l, (int)Dx, (int)Dm, nullptr, Zb.Xt, Dx, Zb.X, l, stream, sk_slab, sSk));
@@ -935,6 +949,93 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
     if (s) CHK(scale_rows_batched(L, s, K, r, batch, stream));
     if (info_out)
         SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return SLIM_OK;
+}
+
+
+// ---- the pieces of the Gram-side fit as separate calls -----------------------------------------------------------------
+// For a layer sharded over several GPUs along its long dimension: every GPU forms the Gram matrix of its shard of E
+// (slim_gemm_nt_bf16 with fp32 output), the sum over the shards goes to one GPU, which runs the subspace iteration
+// (slim_gramfit_iterate) and sends the basis P to all; every GPU projects its shard (slim_gramfit_project: Z = shard x P and
+// the shard's share of the Rayleigh-Ritz matrix Z^T Z, summed over the GPUs again), and after the l x l eigenproblem turns
+// its rows of the factors out (slim_gramfit_factors).  No counterpart in the reference, which is single-GPU.
+extern "C" int64_t slim_gramfit_workspace_bytes(int64_t rows, int64_t l) {
+    if (rows <= 0 || l <= 0) return 0;
+    return fit_ws(nullptr, 1, rows, 8, l).total;
+}
+
+extern "C" int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_iter, uint32_t seed, int flags, int cond_e, void* P,
+                                    void* Pt, int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(C16 && P && Pt && workspace, "slim_gramfit_iterate: null pointer");
+    SLIM_REQUIRE(Dm > 0 && l > 0 && l < Dm && Dm % 8 == 0 && l % 8 == 0 && n_iter >= 0, "slim_gramfit_iterate: bad sizes");
+    SLIM_REQUIRE(2 * (n_iter + 1) + 1 <= SLIM_FIT_INFO_WORDS / 2, "slim_gramfit_iterate: too many iterations");
+    SLIM_REQUIRE(workspace_bytes >= slim_gramfit_workspace_bytes(Dm, l), "slim_gramfit_iterate: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    FitWs w = fit_ws((char*)workspace, 1, Dm, 8, l);
+    SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    const int cond = cond_e > 0 ? (cond_e > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : cond_e) : 9;
+    int a = 0, ninfo = 0;
+    CHK(gram_iterate(w.A, (const bf16_t*)C16, Dm * Dm, 1, Dm, l, n_iter, seed, flags & ~(SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL),
+                     cond, w, w.sketch_slab, (int64_t)SKETCH_MAX_SPLITS * l * Dm, stream, &a, &ninfo));
+    const size_t bytes = (size_t)Dm * l * sizeof(bf16_t);
+    SLIM_HIP(hipMemcpyAsync(P, w.A[a].X, bytes, hipMemcpyDeviceToDevice, st));
+    SLIM_HIP(hipMemcpyAsync(Pt, w.A[a].Xt, bytes, hipMemcpyDeviceToDevice, st));
+    if (info_out) SLIM_HIP(hipMemcpyAsync(info_out, w.info, SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return SLIM_OK;
+}
+
+// Z [rows, l] = X P and Z^T, M32 [l, l] = Z^T Z (fp32): X [rows, Dm] is the shard of E (or of E^T) whose columns the basis P
+// [Dm, l] (given as Pt [l, Dm]) spans
+extern "C" int slim_gramfit_project(const void* X, int64_t rows, int64_t Dm, int l, const void* Pt, void* Z, void* Zt, float* M32,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(X && Pt && Z && Zt && M32 && workspace, "slim_gramfit_project: null pointer");
+    SLIM_REQUIRE(rows > 0 && Dm > 0 && l > 0 && rows % 8 == 0 && Dm % 8 == 0 && l % 8 == 0, "slim_gramfit_project: bad sizes");
+    SLIM_REQUIRE(workspace_bytes >= slim_gramfit_workspace_bytes(rows, l), "slim_gramfit_project: workspace too small");
+    FitWs w = fit_ws((char*)workspace, 1, rows, 8, l);
+    CHK(nt(1, (const bf16_t*)Pt, Dm, 0, (const bf16_t*)X, Dm, 0, l, (int)rows, (int)Dm, nullptr, (bf16_t*)Zt, rows, (bf16_t*)Z, l, stream,
+           w.sketch_slab, (int64_t)SKETCH_MAX_SPLITS * l * rows));
+    w.G = M32;
+    return gram((const bf16_t*)Zt, rows, l, w, nullptr, stream);
+}
+
+// The factors from the eigenvectors of the Rayleigh-Ritz matrix (vecs [l, l]: row l-1-i = eigenvector of the i-th largest
+// eigenvalue, evals [l] ascending, as slim_eigh_tail_f32 leaves them):
+//   right != 0 (P spans right singular vectors, Dm = K):  dm_out = L = P W S [K, r],  rows_out = U rows = Z W S^-1
+//   right == 0 (P spans left singular vectors, Dm = N):   dm_out = U = P W [N, r],    rows_out = L rows = Z W
+// dm_out_t / rows_out_t (optional): the transposes.  S [r] (optional): singular values.  s (optional): the saliency
+// scales of L's rows (length Dm when right, else rows); L is divided by bf16(s) as slim_lowrank_fit does.  info (optional,
+// SLIM_FIT_INFO_WORDS words): its last word receives the conditioning check of slim_lowrank_fit for an iteration sized for
+// cond_e (0: the default).
+extern "C" int slim_gramfit_factors(int right, const void* P, const void* Z, int64_t Dm, int64_t rows, int l, int r,
+                                    const float* vecs, const float* evals, const float* s, void* dm_out, void* dm_out_t,
+                                    void* rows_out, void* rows_out_t, float* S, int cond_e, int32_t* info, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(P && Z && vecs && evals && dm_out && rows_out && workspace, "slim_gramfit_factors: null pointer");
+    SLIM_REQUIRE(!s || !(right ? dm_out_t : rows_out_t), "slim_gramfit_factors: the transpose of a scaled factor is not produced");
+    SLIM_REQUIRE(Dm > 0 && rows > 0 && l > 0 && r > 0 && r <= l && Dm % 8 == 0 && rows % 8 == 0 && l % 8 == 0 && r % 8 == 0,
+                 "slim_gramfit_factors: bad sizes");
+    SLIM_REQUIRE(workspace_bytes >= 2 * al256((int64_t)l * l * 2), "slim_gramfit_factors: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    bf16_t* T16 = (bf16_t*)workspace;
+    bf16_t* T16b = (bf16_t*)((char*)workspace + al256((int64_t)l * l * 2));
+    const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, 1);
+    if (info) {     // the conditioning the spectrum shows against the level the iteration was sized for -> last status word
+        cond_check_kernel<<<1, 64, 0, st>>>(evals, l, r, 1, cond_e > 0 ? cond_e : 9, info);
+        SLIM_LAUNCH_CHECK();
+    }
+    if (right) {
+        top_eigvecs_kernel<<<grid, 256, 0, st>>>(vecs, evals, l, r, nullptr, S, T16, T16b);
+        SLIM_LAUNCH_CHECK();
+        CHK(nt(1, (const bf16_t*)P, l, 0, T16b, l, 0, (int)Dm, r, l, nullptr, (bf16_t*)dm_out, r, (bf16_t*)dm_out_t, Dm, stream));
+        CHK(nt(1, (const bf16_t*)Z, l, 0, T16, l, 0, (int)rows, r, l, nullptr, (bf16_t*)rows_out, r, (bf16_t*)rows_out_t, rows, stream));
+        if (s) CHK(scale_rows_batched(dm_out, s, Dm, r, 1, stream));
+    } else {
+        top_eigvecs_kernel<<<grid, 256, 0, st>>>(vecs, evals, l, r, T16, S, nullptr, nullptr);
+        SLIM_LAUNCH_CHECK();
+        CHK(nt(1, (const bf16_t*)P, l, 0, T16, l, 0, (int)Dm, r, l, nullptr, (bf16_t*)dm_out, r, (bf16_t*)dm_out_t, Dm, stream));
+        CHK(nt(1, (const bf16_t*)Z, l, 0, T16, l, 0, (int)rows, r, l, nullptr, (bf16_t*)rows_out, r, (bf16_t*)rows_out_t, rows, stream));
+        if (s) CHK(scale_rows_batched(rows_out, s, rows, r, 1, stream));
+    }
     return SLIM_OK;
 }
 

@@ -465,6 +465,58 @@ def lowrank_fit_back(ctx, d, e, Q, vecs, s=None, tail_info=None):
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
 
+# ---- the Gram-side fit in pieces (layers sharded over several GPUs) ---------------------------------------
+def gramfit_iterate(C16, l, n_iter, seed=0, flags=0, cond_e=0):
+    """Subspace iteration on the symmetric bf16 matrix C16 [Dm, Dm] -> (P [Dm, l], Pt [l, Dm], info int32 [64])."""
+    C16 = _chk(C16, BF16, "C16")
+    Dm = C16.shape[0]
+    P = torch.empty(Dm, l, dtype=BF16, device=C16.device)
+    Pt = torch.empty(l, Dm, dtype=BF16, device=C16.device)
+    info = torch.empty(64, dtype=torch.int32, device=C16.device)
+    ws = _ws(_lib.query("slim_gramfit_workspace_bytes", Dm, l), C16.device)
+    _lib.call("slim_gramfit_iterate", _p(C16), Dm, int(l), int(n_iter), int(seed), int(flags), int(cond_e), _p(P), _p(Pt), _p(info),
+              _p(ws), ws.numel(), _stream())
+    return P, Pt, info
+
+
+def gramfit_project(X, Pt):
+    """X [rows, Dm] (a shard of E or E^T), Pt [l, Dm] -> (Z = X P [rows, l], Zt [l, rows], M32 = Z^T Z fp32 [l, l])."""
+    X = _chk(X, BF16, "X")
+    Pt = _chk(Pt, BF16, "Pt")
+    rows, Dm = X.shape
+    l = Pt.shape[0]
+    Z = torch.empty(rows, l, dtype=BF16, device=X.device)
+    Zt = torch.empty(l, rows, dtype=BF16, device=X.device)
+    M32 = torch.empty(l, l, dtype=torch.float32, device=X.device)
+    ws = _ws(_lib.query("slim_gramfit_workspace_bytes", rows, l), X.device)
+    _lib.call("slim_gramfit_project", _p(X), rows, Dm, l, _p(Pt), _p(Z), _p(Zt), _p(M32), _p(ws), ws.numel(), _stream())
+    return Z, Zt, M32
+
+
+def gramfit_factors(right, P, Z, vecs, evals, r, s=None, want_dm_t=False, want_rows_t=False, info=None, cond_e=0):
+    """The factors from the Rayleigh-Ritz eigenvectors; see slim_gramfit_factors.  Returns (dm_out [Dm, r], dm_out_t |
+    None, rows_out [rows, r], rows_out_t | None, S [r]).  info (int32 [64], optional): its last word receives the
+    conditioning check for an iteration sized for cond_e."""
+    P = _chk(P, BF16, "P")
+    Z = _chk(Z, BF16, "Z")
+    vecs = _chk(vecs, torch.float32, "vecs")
+    evals = _chk(evals, torch.float32, "evals")
+    Dm, l = P.shape
+    rows = Z.shape[0]
+    dev = P.device
+    dm_out = torch.empty(Dm, r, dtype=BF16, device=dev)
+    dm_t = torch.empty(r, Dm, dtype=BF16, device=dev) if want_dm_t else None
+    rows_out = torch.empty(rows, r, dtype=BF16, device=dev)
+    rows_t = torch.empty(r, rows, dtype=BF16, device=dev) if want_rows_t else None
+    S = torch.empty(r, dtype=torch.float32, device=dev)
+    if s is not None:
+        s = _chk(s, torch.float32, "s")
+    ws = _ws(2 * ((l * l * 2 + 255) // 256 * 256), dev)
+    _lib.call("slim_gramfit_factors", int(bool(right)), _p(P), _p(Z), Dm, rows, l, int(r), _p(vecs), _p(evals), _p(s), _p(dm_out),
+              _p(dm_t), _p(rows_out), _p(rows_t), _p(S), int(cond_e), _p(info), _p(ws), ws.numel(), _stream())
+    return dm_out, dm_t, rows_out, rows_t, S
+
+
 def scale_rows(L, s):
     """In place: L[k, :] = bf16(L[k, :] / bf16(s[k])) (the division of lora_left by sqrt(scaler_row))."""
     L = _chk(L, BF16, "L")

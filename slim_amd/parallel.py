@@ -1,9 +1,11 @@
 """Multi-GPU partitioning of the compression path: one process per GPU, torch.distributed (RCCL on the
 GPUs, gloo in CPU tests).  The reference has no distributed code; this is new design.
 
-Within one decoder block the linear layers are independent once their calibration statistics exist, so
-they are assigned to ranks by cost; the owner compresses a linear and broadcasts the result (weight,
-adapters, scale), because every rank needs the whole compressed block for the next forward pass."""
+Two partitions of a decoder block's compression.  Layer-level (this file + prune.prune_wanda): the linear layers are
+independent once their calibration statistics exist, so they are assigned to ranks by cost; the owner compresses a
+linear and broadcasts the result (weight, adapters, scale), because every rank needs the whole compressed block for the
+next forward pass.  Row-block level (sharded.py): every linear is cut over all ranks; the collectives it needs are the
+staged wrappers below."""
 import torch
 import torch.distributed as dist
 
@@ -30,7 +32,13 @@ def _staged(group):
     return dist.get_backend(group) == "gloo"
 
 
+def _alone(group):
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+
+
 def broadcast(t, src, group=None):
+    if _alone(group):
+        return t
     if t.is_cuda and _staged(group):
         h = t.cpu()
         dist.broadcast(h, src=src, group=group)
@@ -40,19 +48,79 @@ def broadcast(t, src, group=None):
     return t
 
 
-def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True):
+def _op(op):
+    return {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op]
+
+
+def all_reduce(t, group=None, op="sum"):
+    """In place; t is identical on every rank afterwards."""
+    if _alone(group):
+        return t
+    if t.is_cuda and _staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=_op(op), group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=_op(op), group=group)
+    return t
+
+
+def reduce(t, dst, group=None):
+    """In place sum onto rank dst (the other ranks' tensors are left undefined)."""
+    if _alone(group):
+        return t
+    if t.is_cuda and _staged(group):
+        h = t.cpu()
+        dist.reduce(h, dst=dst, group=group)
+        if dist.get_rank(group) == dst:
+            t.copy_(h)
+    else:
+        dist.reduce(t, dst=dst, group=group)
+    return t
+
+
+def all_gather(t, group=None):
+    """[world, *t.shape]: every rank's t (same shape and dtype everywhere)."""
+    t = t.contiguous()
+    if _alone(group):
+        return t.unsqueeze(0)
+    world = dist.get_world_size(group)
+    if _staged(group):
+        h = t.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.stack(parts).to(t.device)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True, scale_dtype=torch.float32,
+                    has_left_mask=False):
     """Broadcast one compressed linear from its owner.  shapes = (N, K, r).  Non-owners allocate receive
-    buffers; afterwards every rank holds weight.data [N, K], lora_left [K, r], lora_right [r, N] and
-    scaling_factor (1, 1)."""
+    buffers; afterwards every rank holds weight.data [N, K], lora_left [K, r], lora_right [r, N],
+    scaling_factor (1, 1) in scale_dtype (fp32 under SLiM-Quant, bf16 under abs-max: what the owner's quantiser
+    leaves) and, for pruned adapters, lora_left_mask [K, r] (bool)."""
     N, K, r = shapes
     dt = lin.weight.dtype
     if owner != rank:
         lin.weight.data = torch.empty(N, K, dtype=dt, device=device)
         lin.lora_left = torch.nn.Parameter(torch.empty(K, r, dtype=dt, device=device), requires_grad=False)
         lin.lora_right = torch.nn.Parameter(torch.empty(r, N, dtype=dt, device=device), requires_grad=False)
-        lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=device) if has_scale else None
-    for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data) + ((lin.scaling_factor,) if has_scale else ()):
+        lin.scaling_factor = torch.empty(1, 1, dtype=scale_dtype, device=device) if has_scale else None
+        if has_left_mask:
+            lin.lora_left_mask = torch.empty(K, r, dtype=torch.bool, device=device)
+    elif has_scale and lin.scaling_factor.dtype != scale_dtype:
+        raise TypeError(f"scaling factor of the owner is {lin.scaling_factor.dtype}, the exchange expects {scale_dtype}")
+    tensors = [lin.weight.data, lin.lora_left.data, lin.lora_right.data]
+    if has_scale:
+        tensors.append(lin.scaling_factor)
+    for t in tensors:
         broadcast(t, owner, group)
+    if has_left_mask:
+        m8 = lin.lora_left_mask.to(torch.uint8)         # bool has no reduction/broadcast support in every backend
+        broadcast(m8, owner, group)
+        lin.lora_left_mask = m8.bool()
     return lin
 
 

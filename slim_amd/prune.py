@@ -52,6 +52,9 @@ PREPARE_PHASE = os.environ.get("SLIM_PREPARE_PHASE", "0") == "1"
 # which of the side streams carry the chains when there are at most that many: HIP spreads a process's streams over four
 # in-order hardware queues, and these four of the seven side streams sit on four different ones
 GROUP_STREAM_IDS = [int(x) for x in os.environ.get("SLIM_GROUP_STREAMS", "0,1,2,6").split(",") if x != ""]
+# several GPUs: cut every linear of a block into row (or column) blocks over all ranks (sharded.py) where the recipe
+# allows it; SLIM_SHARD_LINEARS=0: whole linears on their owners
+SHARD_LINEARS = os.environ.get("SLIM_SHARD_LINEARS", "1") == "1"
 _side_streams = {}
 
 
@@ -304,15 +307,22 @@ def compress_linears(items, dev, *args, **kwargs):
 def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
                      quantize_lora=False, pad_lora=False, lora_tile_size=256, separate_lora=True, quantize_first=True,
                      scale_important_weights=False, tiled_weight_quantization=False, callback=None, describe=None,
-                     n_streams=None):
+                     n_streams=None, shard=False):
     """Compress the linears of one block after their statistics pass (the body of the per-linear loop of
     prune.py:256-357).  items: list of (name, nn.Linear, WrappedGPT) with block_stats() already applied.
 
     With adapters the work runs in three phases, each spread over the side streams: (1) per linear: mask,
     first scale search, error matrix; (2) per group of same-shape linears (q/k/v/o, gate/up): ONE batched
     low-rank fit, so the launch count and the eigen-solve chain are paid once per group; (3) per linear:
-    residual weight, second scale search, re-quantisation, adapter attributes and hook."""
+    residual weight, second scale search, re-quantisation, adapter attributes and hook.
+    shard=True (several ranks, every rank passing the same items): the row-block partition of sharded.py instead."""
     from .lora import (add_lora_prepare, add_lora_fit, add_lora_finish, planned_group_key)
+    if shard:
+        # every rank holds a block of every linear (the caller has checked sharded.supported on these items)
+        from . import sharded
+        sharded.compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank, slim_lora,
+                                         lora_tile_size if (quantize_lora or pad_lora) else None, callback, describe)
+        return
 
     def mask_of(lin, wrapped):
         if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
@@ -517,9 +527,10 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
     run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
 
 
-def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale, separate_lora=True):
-    """Every rank receives the compressed form of the linears it does not own (weight, adapters, scale) and gives
-    them the attributes and the hook the owner's copy has."""
+def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale, separate_lora=True,
+                    scale_dtype=torch.float32, prune_lora=False):
+    """Every rank receives the compressed form of the linears it does not own (weight, adapters, scale, mask of pruned
+    adapters) and gives them the attributes and the hook the owner's copy has."""
     from .lora import lora_rank as rank_of
     for j, n in enumerate(names):
         lin = subset[n]
@@ -527,7 +538,8 @@ def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora
         if lora_rank > 0. and separate_lora:
             r = min(rank_of((N, K), lora_rank, lora_tile_size if tiled_rank else None), min(N, K))
             mine = owner[j] == rank
-            parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale)
+            parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale, scale_dtype=scale_dtype,
+                                     has_left_mask=prune_lora)
             if not mine:
                 lin.lora_rank = torch.tensor(r)
                 lin.register_forward_hook(add_lora_hook)
@@ -535,7 +547,7 @@ def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora
             parallel.broadcast(lin.weight.data, owner[j])
             if has_scale:
                 if owner[j] != rank:
-                    lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=dev)
+                    lin.scaling_factor = torch.empty(1, 1, dtype=scale_dtype, device=dev)
                 parallel.broadcast(lin.scaling_factor, owner[j])
 
 
@@ -606,19 +618,25 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                     (lambda w: min(_rank_rule((w.rows, w.columns), lora_rank, tile_rule), w.rows, w.columns)) if lora_rank > 0. else None)
 
         names = list(subset)
-        owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)
-        compress_linears(
-            [(n, subset[n], wrapped_layers[n]) for j, n in enumerate(names) if owner[j] == rank], dev, prune_n, prune_m,
-            sparsity_ratio=sparsity_ratio, quantizer=quantizer,
-            lora_rank=lora_rank, slim_lora=slim_lora, prune_lora=prune_lora, quantize_lora=quantize_lora, pad_lora=pad_lora,
-            lora_tile_size=lora_tile_size, separate_lora=separate_lora, quantize_first=quantize_first,
-            scale_important_weights=scale_important_weights, tiled_weight_quantization=tiled_weight_quantization,
-            callback=(lambda name, lin, wrapped, i=i: LAYER_CALLBACK(i, name, lin, wrapped)) if LAYER_CALLBACK else None,
-            describe=lambda name, i=i: progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}"))
-
-        if world > 1:
-            _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
-                            quantizer is not None and not tiled_weight_quantization, separate_lora)
+        opts = dict(sparsity_ratio=sparsity_ratio, quantizer=quantizer,
+                    lora_rank=lora_rank, slim_lora=slim_lora, prune_lora=prune_lora, quantize_lora=quantize_lora, pad_lora=pad_lora,
+                    lora_tile_size=lora_tile_size, separate_lora=separate_lora, quantize_first=quantize_first,
+                    scale_important_weights=scale_important_weights, tiled_weight_quantization=tiled_weight_quantization,
+                    callback=(lambda name, lin, wrapped, i=i: LAYER_CALLBACK(i, name, lin, wrapped)) if LAYER_CALLBACK else None,
+                    describe=lambda name, i=i: progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}"))
+        everything = [(n, subset[n], wrapped_layers[n]) for n in names]
+        from . import sharded
+        if world > 1 and SHARD_LINEARS and sharded.supported(everything, world, prune_n, prune_m, quantizer, lora_rank, slim_lora,
+                                                             prune_lora, separate_lora, quantize_first, tile_rule):
+            # every linear cut into blocks over all ranks; every rank ends with the whole compressed block
+            compress_linears(everything, dev, prune_n, prune_m, shard=True, **opts)
+        else:
+            owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)
+            compress_linears([it for j, it in enumerate(everything) if owner[j] == rank], dev, prune_n, prune_m, **opts)
+            if world > 1:
+                _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
+                                quantizer is not None and not tiled_weight_quantization, separate_lora,
+                                torch.float32 if slim_quant else torch.bfloat16, prune_lora)
 
         progress_bar.set_description(f"Layer {i} - Evaluating Output")
         _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)

@@ -1,6 +1,9 @@
-"""The sample-sharded, layer-partitioned driver (two ranks, gloo, both on the one GPU of the test box) must leave
-exactly what the single-process driver leaves: statistics are gathered into sample order before the recurrence
-and every linear is compressed by exactly one rank with the same kernels, so the result is bit-identical."""
+"""The sample-sharded driver on two ranks (gloo, both on the one GPU of the test box) against the single-process driver.
+Statistics are gathered into sample order before the recurrence, so they are bit-identical.  With whole linears on
+their owners (SLIM_SHARD_LINEARS=0) every linear is compressed by exactly one rank with the same kernels: the result is
+bit-identical.  With every linear cut into row blocks over the ranks (the default) the masks of the first block are
+bit-identical and the rest agrees to the accuracy of the low-rank fit (tests/test_sharded_gpu.py states the tolerance
+per linear; here the whole model is driven through slim.prune.prune_and_quantize)."""
 import os
 import subprocess
 import sys
@@ -49,17 +52,33 @@ if world > 1:
 '''
 
 
-def test_two_ranks_equal_one(tmp_path):
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_ranks_equal_one(tmp_path, shard):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", SLIM_SHARD_LINEARS="1" if shard else "0")
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     subprocess.run([sys.executable, str(worker), ROOT, one], check=True, env=env, timeout=300)
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                     "127.0.0.1", "--master-port", "29611", str(worker), ROOT, two], check=True, env=env, timeout=300)
     a, b = torch.load(one), torch.load(two)
     assert a.keys() == b.keys() and len(a) == 2 * 7 * 4
+    if not shard:
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        return
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+        if k.endswith(".weight"):
+            za, zb = a[k] == 0, b[k] == 0
+            assert bool((zb.reshape(-1, 4).sum(1) >= 2).all()), k                    # 2:4 everywhere
+            differ = (a[k] != b[k]).float().mean().item()
+            # block 0 sees identical statistics: the same mask, and codes that differ only where the slightly different
+            # factors tip a rounding; block 1 sees the (slightly different) outputs of block 0
+            if k.startswith("0."):
+                assert (za != zb).float().mean().item() < 0.02, k
+            assert differ < (0.1 if k.startswith("0.") else 0.5), (k, differ)
+        if k.endswith(".sf"):
+            assert abs(float(b[k]) / float(a[k]) - 1) < 0.05, k
