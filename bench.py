@@ -8,9 +8,12 @@ synthetic bf16 activations -> shift_zeros -> saliency + 2:4 mask -> scale search
 matrix -> rank-512 low-rank fit -> residual -> second scale search + re-quantisation -> 2:4 4-bit packing.
 Metric: weight GB/s compressed = sum(2 N K bytes of the linears compressed) / wall-clock.
 
-N GPUs: the 7 independent linears of the block are partitioned over the ranks by cost (longest
-processing time first) and the compressed shards (weight + adapters) are broadcast from their owners
-over RCCL, i.e. fixed total work per step ("strong" scaling).
+N GPUs: fixed total work per step ("strong" scaling), one block compressed by all ranks together, every rank ending with
+the whole compressed block.  Two partitions exist (--partition): "rows" cuts every linear into row (or column) blocks
+over all ranks, with the calibration samples sharded too (histogram and Rayleigh-Ritz all-reduce, Gram reduce, all-gather
+of the compressed blocks: slim_amd/sharded.py); "layers" deals whole linears to ranks by cost and broadcasts the results.
+The default "auto" times one step of each after the warm-up and keeps the faster one for the timed steps (both timings
+and the choice are reported).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
@@ -129,6 +132,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured end-to-end compression of the whole LLaMA-2-7B-shaped "
                                                          "model (slim.prune.prune_and_quantize, ~15 s) after the timed steps")
     ap.add_argument("--streams", type=int, default=7, help="HIP streams the linears of a block are spread over")
+    ap.add_argument("--partition", default="auto", choices=["auto", "rows", "layers"],
+                    help="N > 1: how the block is split over the ranks (see the module docstring)")
     ap.add_argument("--rehearse-backend", default=None,
                     help="rehearsal of the multi-rank path on fewer GPUs than ranks: process-group backend (gloo); ranks "
                          "then share devices round-robin and the numbers mean nothing")
@@ -167,26 +172,39 @@ def main():
     costs = [n * k for _, n, k, _ in LLAMA2_7B_BLOCK]
     owner = partition(costs, world)
     mine = [i for i in range(len(LLAMA2_7B_BLOCK)) if owner[i] == rank]
+    if args.partition != "auto":
+        modes = [args.partition]            # (rows on one GPU: the sharded code path without exchange, a tuning aid)
+    else:
+        modes = ["layers"] if world == 1 else ["rows", "layers"]
+    if "rows" in modes and args.nsamples % world:
+        raise SystemExit(f"--nsamples {args.nsamples} must be divisible by the number of ranks ({world})")
 
     # ---- resident synthetic inputs ------------------------------------------------------------------
-    lins, acts = {}, {}
+    lins, acts, acts_local = {}, {}, {}
+    n_local = args.nsamples // world
     for i, (name, n, k, src) in enumerate(LLAMA2_7B_BLOCK):
         lin = torch.nn.Linear(k, n, bias=False, device=dev, dtype=torch.bfloat16)
         lin.weight.requires_grad_(False)
         lins[i] = lin
-        if i in mine and src not in acts:
-            acts[src] = synth_acts(args.nsamples, args.seqlen, k, 1 + len(acts), dev)
+        seed = 1 + ["attn", "o", "mlp", "down"].index(src)
+        if "layers" in modes and i in mine and src not in acts:
+            acts[src] = synth_acts(args.nsamples, args.seqlen, k, seed, dev)
+        if "rows" in modes and src not in acts_local:
+            # this rank's contiguous share of the calibration samples (the driver shards the block forwards the same way)
+            acts_local[src] = (acts[src][rank * n_local:(rank + 1) * n_local] if src in acts
+                               else synth_acts(n_local, args.seqlen, k, 1000 * rank + seed, dev))
     W0 = {i: synth_weight(n, k, 100 + i, dev) for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK)}
     block_bytes = sum(2.0 * n * k for _, n, k, _ in LLAMA2_7B_BLOCK)
 
     from slim_amd import ops, parallel
     from slim_amd.prune import compress_linears, block_stats
-    from slim_amd.layerwrapper import shared_inputs
+    from slim_amd.layerwrapper import shared_inputs, WrappedGPT
     from slim_amd.quantization.quantization import Quantizer
 
     packed = {}
+    recipe = dict(sparsity_ratio=0.5, lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=256)
 
-    def step(n_streams=None):
+    def step_layers(n_streams=None):
         wrapped = {}
         # statistics pass (in the driver: hooks of the block forward).  As in a decoder block, q/k/v and gate/up
         # read the same activation tensor, whose column sums the hooks then compute once.
@@ -201,8 +219,8 @@ def main():
             lins[i]._forward_hooks.clear()
         # the per-linear body of slim_amd.prune.prune_wanda after the statistics pass
         compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in mine], dev, 2, 4,
-                         sparsity_ratio=0.5, quantizer=Quantizer("weight", num_bits=4, slim_quant=True), lora_rank=0.1, slim_lora=True,
-                         quantize_lora=True, lora_tile_size=256, n_streams=args.streams if n_streams is None else n_streams)
+                         quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
+                         n_streams=args.streams if n_streams is None else n_streams, **recipe)
         # pack: the compressed weight in its 2:4 4-bit storage form (0.375 byte per element); the status words are read
         # after the timed region
         for i in mine:
@@ -219,6 +237,28 @@ def main():
                 for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data):
                     parallel.broadcast(t, owner[i])          # RCCL broadcast (host-staged only under a gloo rehearsal)
 
+    def step_rows(n_streams=None):
+        # statistics: every rank sums its share of the samples, the per-sample sums are gathered into sample order and
+        # folded with the reference's recurrence on every rank (bit-identical to a single-GPU pass)
+        wrapped = {}
+        with shared_inputs():
+            for i in range(len(LLAMA2_7B_BLOCK)):
+                lins[i].weight.data = W0[i]
+                lins[i]._forward_hooks.clear()
+                wrapped[i] = WrappedGPT(lins[i], defer=True)
+                wrapped[i].add_batch(acts_local[LLAMA2_7B_BLOCK[i][3]], None, per_sample=True)
+        for i in wrapped:
+            wrapped[i].finish_deferred(parallel.gather_sample_stats)
+            wrapped[i].scaler_row = ops.shift_zeros(wrapped[i].scaler_row)
+        block_stats(list(wrapped.values()))
+        compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in wrapped], dev, 2, 4,
+                         quantizer=Quantizer("weight", num_bits=4, slim_quant=True), shard=True, **recipe)
+        for i in wrapped:                   # the storage form of every linear is made once, round-robin over the ranks
+            if i % world == rank:
+                packed[i] = ops.pack24(lins[i].weight.data, lins[i].scaling_factor, check=False)
+
+    steps = {"layers": step_layers, "rows": step_rows}
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -228,15 +268,34 @@ def main():
     for item in filter(None, args.gemm_family_tile.split(",")):
         fam, tile = item.split(":")
         _lib.query("slim_gemm_set_family_tile", int(fam), int(tile))
+    def timed(fn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cpu" if args.rehearse_backend else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    trial = {}
+    if len(modes) > 1:
+        # one untimed step of each partition (first-call costs), then one timed step of each: the faster one runs the
+        # benchmark.  The times are maxima over the ranks, so every rank takes the same decision.
+        for m in modes:
+            steps[m]()
+            trial[m] = timed(steps[m], 1) * 1e3
+        mode = min(modes, key=lambda m: trial[m])
+    else:
+        mode = modes[0]
+    step = steps[mode]
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    for i in mine:
+    dt = timed(step, args.steps)
+    for i in packed:
         ops.pack24_raise(int(packed[i][2].item()))
     # The same steps once more with the in-library timer on (a HIP-event pair around every launch, on the launch's own
     # stream): the per-family table.  Kept out of the timed region above because the event packets themselves cost
@@ -256,7 +315,7 @@ def main():
     prof_single = None
     if world == 1:
         _lib.profile_enable(True)
-        step(1)
+        step(1) if mode == "layers" else step()
         barrier()
         prof_single = _lib.profile_summary()
         _lib.profile_enable(False)
@@ -269,16 +328,11 @@ def main():
         grouped = _P.GROUP_FITS
         _P.GROUP_FITS = False
         _lib.profile_enable(True)
-        step(1)
+        step(1) if mode == "layers" else step()
         barrier()
         prof_problems = _lib.profile_summary()
         _lib.profile_enable(False)
         _P.GROUP_FITS = grouped
-    if world > 1:
-        t = torch.tensor([dt], device="cpu" if args.rehearse_backend else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = block_bytes * args.steps / dt / 1e9
@@ -328,7 +382,11 @@ def main():
             "config": {"workload": ("SUBSET %s (tuning run, not the benchmark workload) of: " % args.only if args.only else "") + "LLaMA-2-7B-shaped decoder block (7 linears, 0.405 GB bf16), SLiM recipe: wanda 2:4 + "
                                    "SLiM-Quant 4-bit + lora_rank 0.1 (r=512, tile 256), "
                                    f"{args.nsamples}x{args.seqlen} synthetic calibration activations resident in HBM",
-                       "partition": f"layer-level over {world} rank(s)" + (" + RCCL broadcast of shards" if world > 1 else ""),
+                       "partition": ("one GPU" if world == 1 else
+                                     f"row blocks of every linear over {world} ranks, samples sharded; histogram / Rayleigh-Ritz "
+                                     "all-reduce, Gram reduce, all-gather of compressed blocks" if mode == "rows" else
+                                     f"whole linears over {world} ranks by cost + broadcast of the compressed linears"),
+                       "partition_trial_ms": {m: round(v, 2) for m, v in trial.items()} or None,
                        "compression_only_extrapolated_s": ms_per_step * 32 / 1e3,
                        "ms_per_step_with_event_timers": dt_instrumented / args.steps * 1e3},
             "roofline": roofline,

@@ -128,8 +128,10 @@ def gather_sample_stats(local_sumsq, group=None):
     """All-gather per-sample column sums of squares ([n_local, K] fp32 each) into sample order
     [n_local * world, K], so that every rank can apply the scaler_row recurrence in the same order as a
     single-GPU run.  Rank r is expected to hold samples r * n_local ... (r + 1) * n_local - 1."""
-    world = dist.get_world_size(group)
     src = local_sumsq.contiguous()
+    if _alone(group):
+        return src
+    world = dist.get_world_size(group)
     if src.is_cuda and _staged(group):
         h = src.cpu()
         parts = [torch.empty_like(h) for _ in range(world)]
