@@ -29,6 +29,8 @@
 #include "common.hpp"
 #include "../../include/slim_hip.h"
 
+typedef __attribute__((ext_vector_type(16))) __bf16 bf16x16;
+
 #define FBN 128
 #define FBK 64
 #define FSTRIDE (FBK + 8)
@@ -175,7 +177,7 @@ struct FwdArgs {
 
 template <int TBM>
 __device__ __forceinline__ void load_a_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
-                                            float div, u16x8 (&r)[(TBM * 8 + 255) / 256]) {
+                                            u16x8 (&r)[(TBM * 8 + 255) / 256]) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < (TBM * 8 + 255) / 256; ++i) {
@@ -183,72 +185,75 @@ __device__ __forceinline__ void load_a_tile(const bf16_t* __restrict__ P, int64_
         if (TBM * 8 < 256 && c >= TBM * 8) break;
         int row = row0 + (c >> 3);
         row = row < rows ? row : rows - 1;
-        const int k = k0 + (c & 7) * 8;
-        if (k < Kd) {
-            r[i] = *(const u16x8*)(P + (int64_t)row * ld + k);
-            if (div != 1.f) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[i][j] = f32_to_bf16(bf16_to_f32(r[i][j]) / div);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[i][j] = 0;
-        }
+        // past the end of the reduction the address is clamped and the value zeroed on the way to LDS (store_a_tile):
+        // a branch around the load would make the compiler wait for every load separately
+        int k = k0 + (c & 7) * 8;
+        k = k < Kd ? k : Kd - 8;
+        r[i] = *(const u16x8*)(P + (int64_t)row * ld + k);
     }
 }
 
+// every element becomes bf16(a / div) when div != 1 (the hook's division by sqrt(rank)); chunks past Kd become zero
 template <int TBM>
-__device__ __forceinline__ void store_a_tile(bf16_t* lds, const u16x8 (&r)[(TBM * 8 + 255) / 256]) {
+__device__ __forceinline__ void store_a_tile(bf16_t* lds, const u16x8 (&r)[(TBM * 8 + 255) / 256], int Kd, int k0, float div) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < (TBM * 8 + 255) / 256; ++i) {
         const int c = t + 256 * i;
         if (TBM * 8 < 256 && c >= TBM * 8) break;
-        *(u16x8*)(lds + (c >> 3) * FSTRIDE + (c & 7) * 8) = r[i];
+        u16x8 v = r[i];
+        if (div != 1.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16(bf16_to_f32(v[j]) / div);
+        }
+        if (k0 + (c & 7) * 8 >= Kd) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0;
+        }
+        *(u16x8*)(lds + (c >> 3) * FSTRIDE + (c & 7) * 8) = v;
     }
 }
 
 __device__ __forceinline__ void load_b_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
                                             u16x8 (&r)[4]) {
     const int t = threadIdx.x;
-    const int kc = (t & 7) * 8;
+    int k = k0 + (t & 7) * 8;
+    k = k < Kd ? k : Kd - 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int row = row0 + (t >> 3) + 32 * i;
         row = row < rows ? row : rows - 1;
-        const int k = k0 + kc;
-        if (k < Kd) r[i] = *(const u16x8*)(P + (int64_t)row * ld + k);
-        else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[i][j] = 0;
-        }
+        r[i] = *(const u16x8*)(P + (int64_t)row * ld + k);
     }
 }
 
-__device__ __forceinline__ void store_b_tile(bf16_t* lds, const u16x8 (&r)[4]) {
+__device__ __forceinline__ void store_b_tile(bf16_t* lds, const u16x8 (&r)[4], int Kd, int k0) {
     const int t = threadIdx.x;
     const int kc = (t & 7) * 8;
+    const bool past = k0 + kc >= Kd;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u16x8*)(lds + ((t >> 3) + 32 * i) * FSTRIDE + kc) = r[i];
+    for (int i = 0; i < 4; ++i) {
+        u16x8 v = r[i];
+        if (past) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0;
+        }
+        *(u16x8*)(lds + ((t >> 3) + 32 * i) * FSTRIDE + kc) = v;
+    }
 }
 
-// expand one thread's 32 packed channels into the LDS B tile
-__device__ __forceinline__ void store_packed_tile(bf16_t* lds, uint2 v, uint32_t m, const uint32_t* __restrict__ pair_lut,
-                                                  const uint2* __restrict__ sel_lut) {
+// Compressed form of the packed weight tile in LDS, as v_smfmac_f32_16x16x64_bf16 consumes it: per row 64 B of kept
+// values (16 groups of 4 dense channels, 2 bf16 each, in channel order) and 8 B of positions (4 bits per group).
+// A thread turns its unit (row, 32 channels: 8 groups) into 32 B of values through the code-byte -> two-levels table.
+#define PSTRIDE 80      // bytes per row: 64 + 8, rounded up to a multiple of 16
+__device__ __forceinline__ void store_packed_tile(bf16_t* lds, uint2 v, uint32_t m, const uint32_t* __restrict__ pair_lut) {
     const int t = threadIdx.x;
     const int row = t & 127, half = t >> 7;
-    uint32_t out[16];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const uint32_t byte = ((g < 4 ? v.x : v.y) >> (8 * (g & 3))) & 0xffu;
-        const uint32_t pair = pair_lut[byte];
-        const uint2 sel = sel_lut[(m >> (4 * g)) & 0xfu];
-        out[2 * g] = __builtin_amdgcn_perm(pair, pair, sel.x);
-        out[2 * g + 1] = __builtin_amdgcn_perm(pair, pair, sel.y);
-    }
-    uint4* dst = (uint4*)(lds + row * FSTRIDE + half * 32);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    char* base = (char*)lds + row * PSTRIDE;
+    uint4* dst = (uint4*)(base + half * 32);
+    dst[0] = make_uint4(pair_lut[v.x & 0xffu], pair_lut[(v.x >> 8) & 0xffu], pair_lut[(v.x >> 16) & 0xffu], pair_lut[v.x >> 24]);
+    dst[1] = make_uint4(pair_lut[v.y & 0xffu], pair_lut[(v.y >> 8) & 0xffu], pair_lut[(v.y >> 16) & 0xffu], pair_lut[v.y >> 24]);
+    *(uint32_t*)(base + 64 + half * 4) = m;
 }
 
 template <int WAVES_M, int FR_M>
@@ -262,7 +267,6 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
     auto As = [&](int b) { return smem + b * BUF; };
     auto Bs = [&](int b) { return smem + b * BUF + TBM * FSTRIDE; };
     uint32_t* pair_lut = (uint32_t*)(smem + 2 * BUF);
-    uint2* sel_lut = (uint2*)(pair_lut + 256);
 
     // consecutive workgroups (one XCD's share of them, see below) walk down the x tiles of one weight
     // column panel, so the packed panel is read from HBM once and then served by that XCD's L2
@@ -270,8 +274,14 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
     const int orig = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
-    const int tiles_m = (g.M + TBM - 1) / TBM;
-    const int tn = wgid / tiles_m, tm = wgid % tiles_m;
+    // ... and inside an XCD's share consecutive workgroups cycle over a group of 8 weight panels before they move to the
+    // next activation tile: the ~64 workgroups an XCD runs at a time then work on 8 weight panels x 8 activation tiles,
+    // every operand tile fetched into that L2 once serves eight of them (walking one panel down all activation tiles
+    // fetched 32 different activation tiles for 2 panels: 3.4 x the traffic from beyond the L2)
+    const int tiles_m = (g.M + TBM - 1) / TBM, tiles_n = g.N / FBN;
+    const int grp = wgid / (8 * tiles_m), in_grp = wgid % (8 * tiles_m);
+    const int gn = min(8, tiles_n - grp * 8);
+    const int tn = grp * 8 + in_grp % gn, tm = in_grp / gn;
     const int row0 = tm * TBM, col0 = tn * FBN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -283,18 +293,12 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
         const int t = threadIdx.x;
         const int c0 = ((int)((uint32_t)t << 28)) >> 28, c1 = ((int)((uint32_t)t << 24)) >> 28;
         pair_lut[t] = (uint32_t)f32_to_bf16((float)c0 / sf) | ((uint32_t)f32_to_bf16((float)c1 / sf) << 16);
-        if (t < 16) {
-            // element e of the group takes bytes (0,1) of the pair if it is the first kept position,
-            // (2,3) if the second, and the constant-zero selector 0x0c otherwise
-            const int p0 = t & 3, p1 = t >> 2;
-            uint32_t s[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] = (e == p0) ? 0x0100u : (e == p1) ? 0x0302u : 0x0c0cu;
-            sel_lut[t] = make_uint2(s[0] | (s[1] << 16), s[2] | (s[3] << 16));
-        }
         __syncthreads();
     }
 
+    // The weight rows are the A operand and the activation rows the B operand of every matrix instruction, so the
+    // accumulators hold y^T: acc[i][j] = rows n of weight row block j x activation rows m of block i, lane (m = fr,
+    // q = fq) register r = y[m][4 q + r of the row block].
     f32x4 acc[FR_M][FR_N];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -305,9 +309,10 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
     zero_acc();
 
     // All fragment reads of a K-step are issued before its MFMAs (and pinned there): left to itself the compiler
-    // interleaves four read-wait-MFMA rounds to save registers, and with one or two waves per SIMD each round's LDS
+    // interleaves read-wait-MFMA rounds to save registers, and with one or two waves per SIMD each round's LDS
     // latency is exposed.
-    auto mma = [&](int cur) {
+    // dense operands on both sides (the adapter product): two 32-channel instructions per K-step
+    auto mma_dense = [&](int cur) {
         const bf16_t* a_base = As(cur) + (wr * FR_M * 16 + fr) * FSTRIDE + fq * 8;
         const bf16_t* b_base = Bs(cur) + (wc * FR_N * 16 + fr) * FSTRIDE + fq * 8;
         bf16x8 af[FBK / 32][FR_M], bfr[FBK / 32][FR_N];
@@ -325,63 +330,101 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
             for (int i = 0; i < FR_M; ++i)
 #pragma unroll
                 for (int j = 0; j < FR_N; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // packed weight: ONE sparse 64-channel instruction per K-step.  A lane (n = fr, kq = fq): the kept values of dense
+    // channels 16 kq .. 16 kq + 15 of row n (16 B) and their sixteen position bits; B lane (m = fr, bq = fq): channels
+    // 8 bq .. + 7 and 32 + 8 bq .. + 7 of activation row m (the operand layout the instruction pairs them in, see the
+    // small-batch kernel below).
+    auto mma_sparse = [&](int cur) {
+        const bf16_t* a_base = As(cur) + (wr * FR_M * 16 + fr) * FSTRIDE + fq * 8;
+        const char* w_base = (const char*)Bs(cur) + (wc * FR_N * 16 + fr) * PSTRIDE;
+        bf16x16 xf[FR_M];
+        bf16x8 wf[FR_N];
+        int idx[FR_N];
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i) {
+            const bf16x8 lo = *(const bf16x8*)(a_base + i * 16 * FSTRIDE), hi = *(const bf16x8*)(a_base + i * 16 * FSTRIDE + 32);
+            xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        }
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) {
+            wf[j] = *(const bf16x8*)(w_base + j * 16 * PSTRIDE + fq * 16);
+            idx[j] = (int)*(const unsigned short*)(w_base + j * 16 * PSTRIDE + 64 + fq * 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+            for (int j = 0; j < FR_N; ++j)
+                acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xf[i], acc[i][j], idx[j], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // main product over K-steps [kb, ke)
-    auto run_main = [&](int kb, int ke) {
+    // Software pipeline of a product's K-steps [kb, ke): the operands of step k + 2 are requested from memory (into one of
+    // two register sets) before step k is multiplied, and the set holding step k + 1 goes to the other LDS buffer after
+    // it.  One K-step of the sparse product is ~300 cycles of matrix instructions per wave, a memory round trip several
+    // times that: with a distance of one step the loop ran at the speed of the round trip.
+    auto pipeline = [&](int kb, int ke, auto& regs, auto load, auto store, auto mma) {
         if (kb >= ke) return;
-        u16x8 ra[NA];
-        uint2 pv;
-        uint32_t pm;
-        const int64_t ktiles = g.K / FBK;
-        auto load_packed = [&](int kt) {
-            const int64_t unit = (((int64_t)tn * ktiles + kt) * 2 + (threadIdx.x >> 7)) * 128 + (threadIdx.x & 127);
-            pv = *(const uint2*)(g.vals + unit * 8);
-            pm = *(const uint32_t*)(g.meta + unit * 4);
-        };
-        load_a_tile<TBM>(g.x, g.ldx, g.M, g.K, row0, kb * FBK, 1.f, ra);
-        load_packed(kb);
-        store_a_tile<TBM>(As(0), ra);
-        store_packed_tile(Bs(0), pv, pm, pair_lut, sel_lut);
+        // Every load and store below is issued unconditionally (past the end the last step is fetched again and never
+        // multiplied): with a load inside a branch the compiler no longer knows how many are outstanding and waits for all
+        // of them, the newest included, before the older set is stored.
+        const int last = ke - 1;
+        load(regs[0], kb);
+        load(regs[1], min(kb + 1, last));
+        store(regs[0], 0, kb);
         __syncthreads();
-        for (int kt = kb; kt < ke; ++kt) {
-            const int cur = (kt - kb) & 1;
-            if (kt + 1 < ke) {
-                load_a_tile<TBM>(g.x, g.ldx, g.M, g.K, row0, (kt + 1) * FBK, 1.f, ra);
-                load_packed(kt + 1);
-            }
-            mma(cur);
-            if (kt + 1 < ke) {
-                store_a_tile<TBM>(As(cur ^ 1), ra);
-                store_packed_tile(Bs(cur ^ 1), pv, pm, pair_lut, sel_lut);
-            }
+        for (int kt = kb; kt < ke; kt += 2) {
+            load(regs[0], min(kt + 2, last));
+            mma(0);
+            store(regs[1], 1, min(kt + 1, last));
+            __syncthreads();
+            load(regs[1], min(kt + 3, last));
+            if (kt + 1 < ke) mma(1);
+            store(regs[0], 0, min(kt + 2, last));
             __syncthreads();
         }
     };
+    struct MainRegs {
+        u16x8 ra[NA];
+        uint2 pv;
+        uint32_t pm;
+    };
+    struct AdRegs {
+        u16x8 ra[NA], rb[4];
+    };
+    // main product over K-steps [kb, ke)
+    auto run_main = [&](int kb, int ke) {
+        MainRegs regs[2];
+        const int64_t ktiles = g.K / FBK;
+        pipeline(kb, ke, regs,
+                 [&](MainRegs& r, int kt) {
+                     load_a_tile<TBM>(g.x, g.ldx, g.M, g.K, row0, kt * FBK, r.ra);
+                     const int64_t unit = (((int64_t)tn * ktiles + kt) * 2 + (threadIdx.x >> 7)) * 128 + (threadIdx.x & 127);
+                     r.pv = *(const uint2*)(g.vals + unit * 8);
+                     r.pm = *(const uint32_t*)(g.meta + unit * 4);
+                 },
+                 [&](MainRegs& r, int buf, int kt) {
+                     store_a_tile<TBM>(As(buf), r.ra, g.K, kt * FBK, 1.f);
+                     store_packed_tile(Bs(buf), r.pv, r.pm, pair_lut);
+                 },
+                 mma_sparse);
+    };
     // second product over its K-steps [kb, ke)
     auto run_ad = [&](int kb, int ke) {
-        if (kb >= ke) return;
-        u16x8 ra[NA], rb[4];
-        load_a_tile<TBM>(g.a, g.lda, g.M, g.Ka, row0, kb * FBK, g.a_div, ra);
-        load_b_tile(g.Bt, g.ldb, g.N, g.Ka, col0, kb * FBK, rb);
-        store_a_tile<TBM>(As(0), ra);
-        store_b_tile(Bs(0), rb);
-        __syncthreads();
-        for (int kt = kb; kt < ke; ++kt) {
-            const int cur = (kt - kb) & 1;
-            if (kt + 1 < ke) {
-                load_a_tile<TBM>(g.a, g.lda, g.M, g.Ka, row0, (kt + 1) * FBK, g.a_div, ra);
-                load_b_tile(g.Bt, g.ldb, g.N, g.Ka, col0, (kt + 1) * FBK, rb);
-            }
-            mma(cur);
-            if (kt + 1 < ke) {
-                store_a_tile<TBM>(As(cur ^ 1), ra);
-                store_b_tile(Bs(cur ^ 1), rb);
-            }
-            __syncthreads();
-        }
+        AdRegs regs[2];
+        pipeline(kb, ke, regs,
+                 [&](AdRegs& r, int kt) {
+                     load_a_tile<TBM>(g.a, g.lda, g.M, g.Ka, row0, kt * FBK, r.ra);
+                     load_b_tile(g.Bt, g.ldb, g.N, g.Ka, col0, kt * FBK, r.rb);
+                 },
+                 [&](AdRegs& r, int buf, int kt) {
+                     store_a_tile<TBM>(As(buf), r.ra, g.Ka, kt * FBK, g.a_div);
+                     store_b_tile(Bs(buf), r.rb, g.Ka, kt * FBK);
+                 },
+                 mma_dense);
     };
 
     const int nk_main = g.vals ? g.K / FBK : 0;
@@ -397,11 +440,9 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
         for (int i = 0; i < FR_M; ++i)
 #pragma unroll
             for (int j = 0; j < FR_N; ++j) {
-                const int col = col0 + wc * FR_N * 16 + j * 16 + fr;
-                const int rbase = row0 + wr * FR_M * 16 + i * 16 + fq * 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rbase + r < g.M) sl[(int64_t)(rbase + r) * g.N + col] = acc[i][j][r];
+                const int m = row0 + wr * FR_M * 16 + i * 16 + fr;
+                const int n = col0 + wc * FR_N * 16 + j * 16 + fq * 4;
+                if (m < g.M) *(f32x4*)(sl + (int64_t)m * g.N + n) = acc[i][j];
             }
         return;
     }
@@ -414,11 +455,10 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
         for (int i = 0; i < FR_M; ++i)
 #pragma unroll
             for (int j = 0; j < FR_N; ++j) {
-                const int col = col0 + wc * FR_N * 16 + j * 16 + fr;
-                const float b = g.bias ? bf16_to_f32(g.bias[col]) : 0.f;
+                const int n = col0 + wc * FR_N * 16 + j * 16 + fq * 4;
                 bf16_t h[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[i][j][r] + b);
+                for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[i][j][r] + (g.bias ? bf16_to_f32(g.bias[n + r]) : 0.f));
                 parked[i][j][0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
                 parked[i][j][1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
             }
@@ -430,25 +470,31 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
         }
         run_ad(0, nk_ad);
     }
+    const bool wide = (g.ldy & 3) == 0 && ((uintptr_t)g.y & 7) == 0;
 #pragma unroll
     for (int i = 0; i < FR_M; ++i)
 #pragma unroll
         for (int j = 0; j < FR_N; ++j) {
-            const int col = col0 + wc * FR_N * 16 + j * 16 + fr;
-            const int rbase = row0 + wr * FR_M * 16 + i * 16 + fq * 4;
+            const int m = row0 + wr * FR_M * 16 + i * 16 + fr;
+            const int n = col0 + wc * FR_N * 16 + j * 16 + fq * 4;
+            if (m >= g.M) continue;
+            bf16_t o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (rbase + r >= g.M) continue;
-                bf16_t o;
                 if (nk_main && nk_ad) {
                     const bf16_t mh = (bf16_t)((parked[i][j][r >> 1] >> (16 * (r & 1))) & 0xffffu);
-                    o = f32_to_bf16(bf16_to_f32(mh) + round_bf16(acc[i][j][r]));
+                    o[r] = f32_to_bf16(bf16_to_f32(mh) + round_bf16(acc[i][j][r]));
                 } else if (nk_main) {
-                    o = (bf16_t)((parked[i][j][r >> 1] >> (16 * (r & 1))) & 0xffffu);
+                    o[r] = (bf16_t)((parked[i][j][r >> 1] >> (16 * (r & 1))) & 0xffffu);
                 } else {
-                    o = f32_to_bf16(acc[i][j][r]);
+                    o[r] = f32_to_bf16(acc[i][j][r]);
                 }
-                g.y[(int64_t)(rbase + r) * g.ldy + col] = o;
+            }
+            bf16_t* dst = g.y + (int64_t)m * g.ldy + n;
+            if (wide) *(uint2*)dst = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = o[r];
             }
         }
 }
@@ -473,7 +519,7 @@ __global__ void linear24_reduce_kernel(const float* __restrict__ slab, int sm, i
 template <int WAVES_M, int FR_M>
 static int launch_linear24(const FwdArgs& g, dim3 grid, hipStream_t st) {
     constexpr int TBM = WAVES_M * FR_M * 16;
-    const int lds = 2 * (TBM + FBN) * FSTRIDE * (int)sizeof(bf16_t) + 256 * 4 + 16 * 8;
+    const int lds = 2 * (TBM + FBN) * FSTRIDE * (int)sizeof(bf16_t) + 256 * 4;
     SLIM_HIP(slim_allow_dynamic_lds((const void*)linear24_kernel<WAVES_M, FR_M>, lds));
     linear24_kernel<WAVES_M, FR_M><<<grid, 256, lds, st>>>(g);
     SLIM_LAUNCH_CHECK();
@@ -505,20 +551,33 @@ static void plan_splits(int tiles, int64_t M, int64_t N, int nk_main, int nk_ad,
 }
 
 // ---------------------------------------------------------------------------------------------
-// small-batch kernel (M <= 16): weights straight to registers
+// small-batch kernel (M <= 16): weights straight to registers, sparse MFMA
 // ---------------------------------------------------------------------------------------------
 // At M <= 16 the weight is streamed once and shared by nobody, so the round trip through LDS and the
-// barrier per K-step of the tiled kernel are pure overhead.  Here a wave owns 32 output rows (two MFMA
-// row blocks) and walks its slice of the reduction in blocks of 128 channels.  The weight is the A operand:
-// lane (n = lane & 15, q = lane >> 4) owns row n and takes, for every block, the 32-channel chunk
-// 128 * kb + 32 * q -- one packed unit (8 B of codes + 4 B of positions), read 128 B-contiguous by the 16
-// lanes of a q group -- which it expands in registers into the four 8-channel A fragments of four MFMAs.
-// The activations are the B operand: lane (m = lane & 15, q) reads x[m][128 * kb + 32 * q + 8 * o ..] for MFMA
-// o, i.e. the channel order inside a block is permuted the same way on both operands, which a dot product
-// does not notice.  C[n][m]: a lane ends with four consecutive output rows of one activation row.
-// Each workgroup (4 waves = 128 rows = one packed tile row) writes fp32 partial sums for its slice of the
-// reduction; linear24_reduce_kernel combines the slices of the main and the adapter product with the
-// rounding points of the reference.
+// barrier per K-step of the tiled kernel are pure overhead.  Here a workgroup owns 16 or 32 output rows
+// (one or two MFMA row blocks) and the WHOLE reduction, which its four waves share block by block (a block =
+// 128 channels; wave w takes blocks w, w + 4, ...); the four partial sums meet in LDS and are added in wave
+// order, so there are no partial sums in memory, no second launch to combine them and no atomics.  The
+// weight is the A operand and the activations the B operand: C[n][m], a lane ends with four consecutive
+// output rows of one activation row.
+//
+// Packed weight: v_smfmac_f32_16x16x64_bf16 takes the 2:4-compressed operand as it is stored -- per lane 8
+// kept values (4 groups of 4 dense channels) and 16 bits of 2-bit positions -- so nothing is expanded to
+// dense: lane (n = lane & 15, q = lane >> 4) reads the packed unit of row n, channels 128 kb + 32 q .. + 32
+// (8 B of codes, 4 B of positions, 128 B-contiguous over the 16 lanes of a q group), turns each code byte
+// into its two bf16 levels with one LDS table lookup, and feeds two instructions (groups 0-3 with the low
+// half of the position word, groups 4-7 with the high half, selected by the instruction's ABID field).
+// Measured operand layout of the instruction (tools/gpu/probe/smfmac_probe.hip): A lane (i, kq) slots
+// 4 s' .. 4 s' + 3 (s' = 0, 1) meet B lane (j, bq = 2 (kq & 1) + s'), elements 8 (kq >> 1) .. + 8, slot s
+// taking element 4 ((s >> 1) & 1) + position_s of them; position_s = bits [2 s + 1 : 2 s] of the 16-bit
+// half-word ABID selects; C lane (j, q) register r = C[4 q + r][j].  So for instruction t of a block, B lane
+// (m, bq) holds x[m][128 kb + 64 h + 32 (bq >> 1) + 16 t + 8 (bq & 1) .. + 8] in elements 8 h .. 8 h + 7.
+//
+// Dense bf16 and 4-bit group-quantised operands (the adapters) use v_mfma_f32_16x16x32_bf16 with the channel
+// order of a block permuted the same way on both operands.
+//
+// A forward with adapters is two launches: [t = x L | the weight product, kept in fp32], then [t R, added to
+// the weight product with the rounding points of the reference].
 struct DecArgs {
     const bf16_t* x;       // [M, Kd] activations (row stride ldx)
     int64_t ldx;
@@ -532,18 +591,25 @@ struct DecArgs {
     const uint8_t* qcodes; // MODE_Q4: 4-bit codes [N, Kd / 2] (even channel in the low nibble) ...
     const bf16_t* qalpha;  // ... and group scales [N, Kd / qblock]; value = bf16(code / 7 * alpha)
     int qblock;
-    int kb_per_slice;      // blocks of 128 channels per reduction slice
-    float* slab;           // [slices][M][N]; this launch writes slices slice0 .. slice0 + gridDim.y - 1
-    int slice0;
+    // what becomes of the product p [M, N]:
+    //   out32 != nullptr:  out32 = p                                     (fp32 [M, N], the first term of a later launch)
+    //   else               y = bf16( first32 ? bf16(first32 + bias) + bf16(p) : p + bias )
+    float* out32;
+    const float* first32;
+    const bf16_t* bias;
+    bf16_t* y;
+    int64_t ldy;
 };
 
-enum { MODE_DENSE = 0, MODE_PACKED24 = 1, MODE_Q4 = 2 };
-template <int MODE>
-__global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
+enum { MODE_NONE = -1, MODE_DENSE = 0, MODE_PACKED24 = 1, MODE_Q4 = 2 };
+
+// lds: 256 words of lookup table, then 4 * RB * 256 floats for the partial sums of the four waves
+template <int MODE, int RB>
+__device__ __forceinline__ void decode_body(const DecArgs& g, const int row0, uint32_t* lds) {
     constexpr bool PACKED = MODE == MODE_PACKED24;
-    __shared__ uint32_t pair_lut[256];
-    __shared__ uint2 sel_lut[16];
-    __shared__ float q4_level[16];     // code / 7 for the sixteen 4-bit codes (index = code & 15)
+    uint32_t* pair_lut = lds;                   // PACKED: 256 entries
+    float* q4_level = (float*)lds;              // Q4: code / 7 for the sixteen 4-bit codes (index = code & 15)
+    float* red = (float*)(lds + 256);
     const int t = threadIdx.x;
     if (MODE == MODE_Q4) {
         if (t < 16) q4_level[t] = (float)((int)((uint32_t)t << 28) >> 28) / 7.0f;
@@ -553,34 +619,27 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
         const float sf = *g.sf;
         const int c0 = ((int)((uint32_t)t << 28)) >> 28, c1 = ((int)((uint32_t)t << 24)) >> 28;
         pair_lut[t] = (uint32_t)f32_to_bf16((float)c0 / sf) | ((uint32_t)f32_to_bf16((float)c1 / sf) << 16);
-        if (t < 16) {
-            const int p0 = t & 3, p1 = t >> 2;
-            uint32_t sv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sv[e] = (e == p0) ? 0x0100u : (e == p1) ? 0x0302u : 0x0c0cu;
-            sel_lut[t] = make_uint2(sv[0] | (sv[1] << 16), sv[2] | (sv[3] << 16));
-        }
         __syncthreads();
     }
     const int lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, q = lane >> 4;
-    const int tn = blockIdx.x;
     const int nkb = (g.Kd + 127) / 128;
-    const int kb0 = blockIdx.y * g.kb_per_slice;
-    const int kb1 = min(kb0 + g.kb_per_slice, nkb);
     const int m_row = fr < g.M ? fr : g.M - 1;
     const bf16_t* xrow = g.x + (int64_t)m_row * g.ldx;
     const int chunks = (g.Kd + 31) / 32;                // Kd is a multiple of 8 (of 64 when packed)
     const int64_t ktiles = g.Kd / 64;
+    const int tn = row0 >> 7, r_tile0 = row0 & 127;     // packed tile row and the first row inside it
 
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     struct Stage {              // operands of one block of 128 channels, as loaded
-        uint2 pv[2];
-        uint32_t pm[2];
-        u16x8 wd[2][4];
+        uint2 pv[RB];
+        uint32_t pm[RB];
+        u16x8 wd[RB][4];
         u16x8 xb[4];
-        uint4 qc[2];            // MODE_Q4: 32 codes of the lane's chunk
-        float qa[2];            //          and their group scale
+        uint4 qc[RB];           // MODE_Q4: 32 codes of the lane's chunk
+        float qa[RB];           //          and their group scale
     };
     auto load_block = [&](Stage& sg, int kb) {
         const int chunk = 4 * kb + q;
@@ -588,26 +647,28 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
         const int k = chunk * 32;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            if (k + 8 * o < g.Kd) sg.xb[o] = *(const u16x8*)(xrow + k + 8 * o);
+            // PACKED: piece (t = o >> 1, h = o & 1) of the sparse instruction's B operand, see above
+            const int kx = PACKED ? 128 * kb + 64 * (o & 1) + 32 * (q >> 1) + 16 * (o >> 1) + 8 * (q & 1) : k + 8 * o;
+            if (kx < g.Kd) sg.xb[o] = *(const u16x8*)(xrow + kx);
             else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sg.xb[o][j] = 0;
             }
         }
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int r_in_tile = wave * 32 + rb * 16 + fr;
+        for (int rb = 0; rb < RB; ++rb) {
+            const int r_in_tile = r_tile0 + rb * 16 + fr;
             if (PACKED) {
                 if (ok) {
                     const int64_t unit = (((int64_t)tn * ktiles + (chunk >> 1)) * 2 + (chunk & 1)) * 128 + r_in_tile;
                     sg.pv[rb] = *(const uint2*)(g.vals + unit * 8);
                     sg.pm[rb] = *(const uint32_t*)(g.meta + unit * 4);
                 } else {
-                    sg.pv[rb] = make_uint2(0u, 0u);
-                    sg.pm[rb] = 0x44444444u;          // positions (0, 1) with zero codes
+                    sg.pv[rb] = make_uint2(0u, 0u);     // zero codes: the positions do not matter
+                    sg.pm[rb] = 0u;
                 }
             } else if (MODE == MODE_Q4) {
-                const int64_t row = (int64_t)tn * 128 + r_in_tile;
+                const int64_t row = (int64_t)row0 + rb * 16 + fr;
                 if (ok) {
                     sg.qc[rb] = *(const uint4*)(g.qcodes + row * (g.Kd / 2) + k / 2);
                     sg.qa[rb] = bf16_to_f32(g.qalpha[row * (g.Kd / g.qblock) + k / g.qblock]);
@@ -616,7 +677,7 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
                     sg.qa[rb] = 0.f;
                 }
             } else {
-                const bf16_t* wrow = g.Wd + ((int64_t)tn * 128 + r_in_tile) * g.ldw + k;
+                const bf16_t* wrow = g.Wd + ((int64_t)row0 + rb * 16 + fr) * g.ldw + k;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     if (k + 8 * o < g.Kd) sg.wd[rb][o] = *(const u16x8*)(wrow + 8 * o);
@@ -629,35 +690,43 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
         }
     };
     auto compute_block = [&](const Stage& sg) {
-        bf16x8 bx[4];
+        u16x8 xs[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            u16x8 v = sg.xb[o];
+            xs[o] = sg.xb[o];
             if (g.a_div != 1.f) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16(bf16_to_f32(v[j]) / g.a_div);
+                for (int j = 0; j < 8; ++j) xs[o][j] = f32_to_bf16(bf16_to_f32(xs[o][j]) / g.a_div);
             }
-            bx[o] = __builtin_bit_cast(bf16x8, v);
         }
+        if (PACKED) {
+            bf16x16 b[2];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+            for (int tt = 0; tt < 2; ++tt) {
+                const bf16x8 lo = __builtin_bit_cast(bf16x8, xs[2 * tt]), hi = __builtin_bit_cast(bf16x8, xs[2 * tt + 1]);
+                b[tt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const uint32_t w0 = sg.pv[rb].x, w1 = sg.pv[rb].y;
+                const uint4 a0 = make_uint4(pair_lut[w0 & 0xffu], pair_lut[(w0 >> 8) & 0xffu], pair_lut[(w0 >> 16) & 0xffu],
+                                            pair_lut[w0 >> 24]);
+                const uint4 a1 = make_uint4(pair_lut[w1 & 0xffu], pair_lut[(w1 >> 8) & 0xffu], pair_lut[(w1 >> 16) & 0xffu],
+                                            pair_lut[w1 >> 24]);
+                acc[rb] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(bf16x8, a0), b[0], acc[rb], (int)sg.pm[rb], 0, 0);
+                acc[rb] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(bf16x8, a1), b[1], acc[rb], (int)sg.pm[rb], 0, 1);
+            }
+            return;
+        }
+        bf16x8 bx[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) bx[o] = __builtin_bit_cast(bf16x8, xs[o]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 bf16x8 a;
-                if (PACKED) {
-                    uint32_t w[4];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int grp = 2 * o + h;
-                        const uint32_t byte = ((grp < 4 ? sg.pv[rb].x : sg.pv[rb].y) >> (8 * (grp & 3))) & 0xffu;
-                        const uint32_t pair = pair_lut[byte];
-                        const uint2 sel = sel_lut[(sg.pm[rb] >> (4 * grp)) & 0xfu];
-                        w[2 * h] = __builtin_amdgcn_perm(pair, pair, sel.x);
-                        w[2 * h + 1] = __builtin_amdgcn_perm(pair, pair, sel.y);
-                    }
-                    const uint4 packed4 = make_uint4(w[0], w[1], w[2], w[3]);
-                    a = __builtin_bit_cast(bf16x8, packed4);
-                } else if (MODE == MODE_Q4) {
+                if (MODE == MODE_Q4) {
                     const uint32_t word = o == 0 ? sg.qc[rb].x : o == 1 ? sg.qc[rb].y : o == 2 ? sg.qc[rb].z : sg.qc[rb].w;
                     u16x8 v;
 #pragma unroll
@@ -672,47 +741,62 @@ __global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs g) {
     };
     // two register stages: the loads of the next block are in flight while the current one is expanded and multiplied
     Stage s0, s1;
-    if (kb0 < kb1) load_block(s0, kb0);
-    for (int kb = kb0; kb < kb1; kb += 2) {
-        if (kb + 1 < kb1) load_block(s1, kb + 1);
+    if (wave < nkb) load_block(s0, wave);
+    for (int kb = wave; kb < nkb; kb += 8) {
+        if (kb + 4 < nkb) load_block(s1, kb + 4);
         compute_block(s0);
-        if (kb + 1 < kb1) {
-            if (kb + 2 < kb1) load_block(s0, kb + 2);
+        if (kb + 4 < nkb) {
+            if (kb + 8 < nkb) load_block(s0, kb + 8);
             compute_block(s1);
         }
     }
-    // C[n][m]: lane holds m = fr, rows n = 4 * q + reg of each row block
-    if (fr < g.M) {
-        float* sl = g.slab + ((int64_t)(g.slice0 + blockIdx.y) * g.M + fr) * g.N + (int64_t)tn * 128 + wave * 32 + 4 * q;
-        *(f32x4*)(sl) = acc[0];
-        *(f32x4*)(sl + 16) = acc[1];
+    // the four waves' partial sums, added in wave order by the first RB waves
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) *(f32x4*)(red + ((wave * RB + rb) * 64 + lane) * 4) = acc[rb];
+    __syncthreads();
+    if (wave >= RB) return;
+    const int rb = wave;
+    f32x4 p = *(const f32x4*)(red + ((0 * RB + rb) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const f32x4 v = *(const f32x4*)(red + ((w * RB + rb) * 64 + lane) * 4);
+        p[0] += v[0], p[1] += v[1], p[2] += v[2], p[3] += v[3];
     }
+    // C[n][m]: the lane holds m = fr, rows n = 4 q .. 4 q + 3 of row block rb
+    if (fr >= g.M) return;
+    const int n0 = row0 + rb * 16 + 4 * q;
+    if (g.out32) {
+        *(f32x4*)(g.out32 + (int64_t)fr * g.N + n0) = p;
+        return;
+    }
+    bf16_t h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float b = g.bias ? bf16_to_f32(g.bias[n0 + r]) : 0.f;
+        const float out = g.first32 ? round_bf16(g.first32[(int64_t)fr * g.N + n0 + r] + b) + round_bf16(p[r]) : p[r] + b;
+        h[r] = f32_to_bf16(out);
+    }
+    *(uint2*)(g.y + (int64_t)fr * g.ldy + n0) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+}
+
+// blocks [0, blocks_a) work on product a (row blocks of RB_A * 16 rows), the rest on product b (MODE_B == MODE_NONE: none)
+template <int MODE_A, int RB_A, int MODE_B, int RB_B>
+__global__ __launch_bounds__(256) void linear24_decode_kernel(DecArgs a, DecArgs b, int blocks_a) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 + 4 * (RB_A > RB_B ? RB_A : RB_B) * 256];
+    const int bx = blockIdx.x;
+    if (MODE_B == MODE_NONE || bx < blocks_a) decode_body<MODE_A, RB_A>(a, bx * RB_A * 16, lds);
+    else decode_body<(MODE_B == MODE_NONE ? MODE_DENSE : MODE_B), RB_B>(b, (bx - blocks_a) * RB_B * 16, lds);
 }
 
 #define DECODE_MAX_M 16
 #define DECODE_MIN_WEIGHT ((int64_t)1 << 26)
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// slices of a decode launch: enough workgroups to fill the chip four times over, at least two blocks per
-// slice, slab traffic (8 B per slice and output) below half of the streamed weight bytes
-static int decode_slices(int64_t M, int64_t N, int64_t Kd, double bytes_per_weight) {
-    const int nkb = (int)((Kd + 127) / 128);
-    const int64_t tiles = N / 128;
-    int64_t want = (1024 + tiles - 1) / tiles;
-    const int64_t cap = (int64_t)((double)N * (double)Kd * bytes_per_weight / (16.0 * (double)M * (double)N));
-    if (want > cap) want = cap;
-    if (want > nkb / 2) want = nkb / 2;
-    if (want < 1) want = 1;
-    const int per = (int)((nkb + want - 1) / want);
-    return (nkb + per - 1) / per;
-}
-
-template <int MODE>
-static int launch_decode(DecArgs g, int slices, hipStream_t st) {
-    const int nkb = (g.Kd + 127) / 128;
-    g.kb_per_slice = (nkb + slices - 1) / slices;
-    dim3 grid((unsigned)(g.N / 128), (unsigned)slices);
-    linear24_decode_kernel<MODE><<<grid, 256, 0, st>>>(g);
+template <int MODE_A, int RB_A, int MODE_B, int RB_B>
+static int launch_decode(const DecArgs& a, const DecArgs& b, hipStream_t st) {
+    const int blocks_a = a.N / (RB_A * 16);
+    const int blocks_b = MODE_B == MODE_NONE ? 0 : b.N / (RB_B * 16);
+    linear24_decode_kernel<MODE_A, RB_A, MODE_B, RB_B><<<(unsigned)(blocks_a + blocks_b), 256, 0, st>>>(a, b, blocks_a);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
@@ -764,8 +848,11 @@ static int run_linear24(FwdArgs g, void* workspace, int64_t workspace_bytes, hip
 }
 
 
-// Workspace: t [M, r128] bf16 (r128 = r rounded up to 128, the width of the tile grid of the first launch)
-// followed by the split-reduction slab, sized for the larger of the two launches.
+// Workspace of the small-batch path: t [M, r128] bf16 (r128 = r rounded up to 128), then the weight product in fp32 [M, N].
+static int64_t decode_ws_bytes(int64_t M, int64_t N, int64_t r) {
+    return round_up(M * round_up(r, 128) * 2, 256) + round_up(M * N * 4, 256);
+}
+
 // Small-batch forward.  The adapter operands are either dense bf16 (LeffT / ReffT) or 4-bit group-quantised
 // (qL_* / qR_*: codes [rows, Kd / 2] and scales [rows, Kd / qblock]), never both.
 static int decode_path(const void* x, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta, const float* sf,
@@ -776,73 +863,62 @@ static int decode_path(const void* x, int64_t ldx, int64_t M, int64_t K, const v
     const bool q4 = qL_codes != nullptr;
     SLIM_REQUIRE(r == 0 || q4 || (LeffT && ReffT && ((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0),
                  "slim_linear24_forward: adapter operands must be 16-byte aligned");
-    // every product goes through fp32 slices + one combine
-    const int64_t t_bytes = round_up(M * r128 * 2, 256);
-    float* slab = (float*)(ws + (r > 0 ? t_bytes : 0));
-    bf16_t* t = nullptr;
-    if (r > 0) {
-        t = (bf16_t*)ws;
-        DecArgs d{};
-        d.x = (const bf16_t*)x;
-        d.ldx = ldx;
-        d.M = (int)M;
-        d.N = (int)r128;
-        d.Kd = (int)K;
-        d.a_div = a_div;
-        d.Wd = (const bf16_t*)LeffT;
-        d.ldw = K;
-        d.qcodes = (const uint8_t*)qL_codes;
-        d.qalpha = (const bf16_t*)qL_alpha;
-        d.qblock = qblock;
-        d.slab = slab;
-        d.slice0 = 0;
-        const int s1 = decode_slices(M, r128, K, q4 ? 0.5 : 2.0);
-        const int rc = q4 ? launch_decode<MODE_Q4>(d, s1, st) : launch_decode<MODE_DENSE>(d, s1, st);
-        if (rc != SLIM_OK) return rc;
-        const int64_t n1 = M * r128;
-        linear24_reduce_kernel<<<(unsigned)ceil_div64(n1, 256), 256, 0, st>>>(slab, 0, s1, (int)M, (int)r128, nullptr, t, r128);
-        SLIM_LAUNCH_CHECK();
+    SLIM_REQUIRE(ldy % 4 == 0 && ((uintptr_t)y % 8) == 0, "slim_linear24_forward: y must be 8-byte aligned with a row stride that is a multiple of 4");
+    bf16_t* t = (bf16_t*)ws;
+    float* first32 = (float*)(ws + round_up(M * r128 * 2, 256));
+    // launch 1: t = x L and, beside it, the weight product
+    DecArgs w{};
+    w.x = (const bf16_t*)x;
+    w.ldx = ldx;
+    w.M = (int)M;
+    w.N = (int)N;
+    w.Kd = (int)K;
+    w.a_div = 1.f;
+    w.vals = (const uint8_t*)vals;
+    w.meta = (const uint8_t*)meta;
+    w.sf = sf;
+    if (r == 0) {
+        w.bias = (const bf16_t*)bias;
+        w.y = (bf16_t*)y;
+        w.ldy = ldy;
+        return launch_decode<MODE_PACKED24, 2, MODE_NONE, 1>(w, w, st);
     }
-    DecArgs d{};
-    d.x = (const bf16_t*)x;
-    d.ldx = ldx;
-    d.M = (int)M;
-    d.N = (int)N;
-    d.Kd = (int)K;
-    d.a_div = 1.f;
-    d.vals = (const uint8_t*)vals;
-    d.meta = (const uint8_t*)meta;
-    d.sf = sf;
-    d.slab = slab;
-    d.slice0 = 0;
-    const int sm = decode_slices(M, N, K, 0.375);
-    int rc = launch_decode<MODE_PACKED24>(d, sm, st);
+    w.out32 = first32;
+    DecArgs l{};
+    l.x = (const bf16_t*)x;
+    l.ldx = ldx;
+    l.M = (int)M;
+    l.N = (int)r128;
+    l.Kd = (int)K;
+    l.a_div = a_div;
+    l.Wd = (const bf16_t*)LeffT;
+    l.ldw = K;
+    l.qcodes = (const uint8_t*)qL_codes;
+    l.qalpha = (const bf16_t*)qL_alpha;
+    l.qblock = qblock;
+    l.y = t;
+    l.ldy = r128;
+    // (the t blocks come first in the grid: each streams a whole row block of L, several times the bytes of a weight block)
+    int rc = q4 ? launch_decode<MODE_Q4, 1, MODE_PACKED24, 2>(l, w, st) : launch_decode<MODE_DENSE, 1, MODE_PACKED24, 2>(l, w, st);
     if (rc != SLIM_OK) return rc;
-    int sa = 0;
-    if (r > 0) {
-        DecArgs a{};
-        a.x = t;
-        a.ldx = r128;
-        a.M = (int)M;
-        a.N = (int)N;
-        a.Kd = (int)r8;
-        a.a_div = a_div;
-        a.Wd = (const bf16_t*)ReffT;
-        a.ldw = r8;
-        a.qcodes = (const uint8_t*)qR_codes;
-        a.qalpha = (const bf16_t*)qR_alpha;
-        a.qblock = qblock;
-        a.slab = slab;
-        a.slice0 = sm;
-        sa = decode_slices(M, N, r8, q4 ? 0.5 : 2.0);
-        rc = q4 ? launch_decode<MODE_Q4>(a, sa, st) : launch_decode<MODE_DENSE>(a, sa, st);
-        if (rc != SLIM_OK) return rc;
-    }
-    const int64_t n2 = M * N;
-    linear24_reduce_kernel<<<(unsigned)ceil_div64(n2, 256), 256, 0, st>>>(slab, sm, sa, (int)M, (int)N, (const bf16_t*)bias,
-                                                                         (bf16_t*)y, ldy);
-    SLIM_LAUNCH_CHECK();
-    return SLIM_OK;
+    // launch 2: t R, added to the weight product
+    DecArgs a{};
+    a.x = t;
+    a.ldx = r128;
+    a.M = (int)M;
+    a.N = (int)N;
+    a.Kd = (int)r8;
+    a.a_div = a_div;
+    a.Wd = (const bf16_t*)ReffT;
+    a.ldw = r8;
+    a.qcodes = (const uint8_t*)qR_codes;
+    a.qalpha = (const bf16_t*)qR_alpha;
+    a.qblock = qblock;
+    a.first32 = first32;
+    a.bias = (const bf16_t*)bias;
+    a.y = (bf16_t*)y;
+    a.ldy = ldy;
+    return q4 ? launch_decode<MODE_Q4, 2, MODE_NONE, 1>(a, a, st) : launch_decode<MODE_DENSE, 2, MODE_NONE, 1>(a, a, st);
 }
 
 extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r) {
@@ -850,14 +926,6 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
     const int64_t r128 = round_up(r, 128);
     const int64_t t_bytes = round_up(M * r128 * 2, 256);
     int64_t slab = 0;
-    if (M <= DECODE_MAX_M) {
-        const int64_t r8 = round_up(r, 8);
-        const int64_t s1 = r ? max(decode_slices(M, r128, K, 2.0), decode_slices(M, r128, K, 0.5)) : 0;
-        const int64_t s2 = decode_slices(M, N, K, 0.375) +
-                           (r ? max(decode_slices(M, N, r8, 2.0), decode_slices(M, N, r8, 0.5)) : 0);
-        const int64_t a = s1 * M * r128 * 4, b = s2 * M * N * 4;
-        slab = a > b ? a : b;       // the tiled path below may be taken instead: keep the larger of the two
-    }
     for (int pass = 0; pass < 2; ++pass) {
         const int64_t n = pass ? N : r128;
         if (n == 0) continue;
@@ -868,7 +936,12 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
         const int64_t b = (int64_t)(sm + sa) * M * n * 4;
         slab = b > slab ? b : slab;
     }
-    return t_bytes + slab;
+    int64_t total = t_bytes + slab;
+    if (M <= DECODE_MAX_M) {     // the small-batch path may be taken instead: keep the larger of the two
+        const int64_t d = decode_ws_bytes(M, N, r);
+        total = d > total ? d : total;
+    }
+    return total;
 }
 
 extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta,
