@@ -64,6 +64,49 @@ def _round_up8(n):
     return -(-int(n) // 8) * 8
 
 
+def deflate_outliers(E, Et, outliers, out=None):
+    """Split the outlier columns of E [N, K] off: with Q_O an orthonormal basis of their span, E = Q_O (Q_O^T E) + E'.
+    outliers = (column indices padded to a multiple of 8, number t of real outliers).  Returns (E' [N, K] (written to
+    `out` when given), Q_O [N, tp], C^T = (Q_O^T E)^T [K, tp], status words of the orthonormalisation); the columns >= t
+    of Q_O are zero.  The outlier columns of E' are not zeroed: they hold what bf16 rounding of Q_O and C left of those
+    columns, which the fit can still pick up."""
+    cols, t = outliers
+    # each column normalised first (their norms differ by orders of magnitude); the padding columns are zeroed, and a
+    # zero column stays zero through Newton-Schulz steps, so the basis spans the real outlier columns only
+    EO = torch.index_select(E, 1, cols).float()
+    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
+    EO[:, t:] = 0
+    EO = EO.to(torch.bfloat16).contiguous()
+    # the normalised columns are close to orthogonal already (random directions in N dimensions): two quintic and
+    # three cubic Newton-Schulz steps bring them to an orthonormal basis of the same span
+    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
+    UO[:, t:] = 0
+    UOt[t:] = 0
+    _, _, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
+    E2 = ops.lowrank_residual(UO, Ct, E, None, out=out)
+    return E2, UO, Ct, info_o
+
+
+def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, info_o=None):
+    """(U [N, r8], Ut [r8, N], L [K, r8], info) from the factors of the randomized fit (rank - t columns wanted) and the
+    exact part of the deflated columns: r8 = rank rounded up to a multiple of 8, columns >= rank zero."""
+    r8 = _round_up8(rank)
+    if t == 0:
+        if r8 != rank:
+            fitU[:, rank:] = 0
+            fitUt[rank:] = 0
+            fitL[:, rank:] = 0
+        return fitU, fitUt, fitL, fit_info
+    LO = ops.scale_rows(Ct, s) if s is not None else Ct
+    U = torch.zeros(N, r8, dtype=fitU.dtype, device=fitU.device)
+    L = torch.zeros(K, r8, dtype=fitU.dtype, device=fitU.device)
+    U[:, :t] = UO[:, :t]
+    U[:, t:rank] = fitU[:, :rank - t]
+    L[:, :t] = LO[:, :t]
+    L[:, t:rank] = fitL[:, :rank - t]
+    return U, ops.transpose(U), L, torch.cat([info_o, fit_info])
+
+
 def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     """Rank-`rank` factors of the error matrix E [N, K] (Et its transpose): U [N, r8], Ut [r8, N], L [K, r8]
     with r8 = rank rounded up to a multiple of 8 and the columns >= rank zero (the MFMA products that consume
@@ -71,56 +114,22 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
 
     E = (benign matrix) x diag(s).  A few channels with very large activations make a few columns of E
     orders of magnitude larger than the rest; bf16 iterates cannot carry both scales, so those columns
-    (`outliers` = (index tensor padded to a multiple of 8, number t of real outliers)) are deflated: with
-    Q_O an orthonormal basis of their span, E = Q_O (Q_O^T E) + E', the first term is kept exactly (rank t)
-    and the randomized fit runs on the well-conditioned remainder E' with rank - t columns.  The fit returns
-    its columns by decreasing singular value, so asking it for a multiple of 8 and dropping the tail is the
-    optimal truncation.  L is returned already divided by bf16(s)."""
+    (`outliers` = (index tensor padded to a multiple of 8, number t of real outliers)) are deflated
+    (deflate_outliers): the exact part is kept (rank t) and the randomized fit runs on the well-conditioned remainder
+    with rank - t columns.  The fit returns its columns by decreasing singular value, so asking it for a multiple of 8
+    and dropping the tail is the optimal truncation.  L is returned already divided by bf16(s)."""
     N, K = E.shape
-    r8 = _round_up8(rank)
-    cols, t = outliers if outliers is not None else (None, 0)
-    if t == 0 or rank - t < 8:
-        over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
-        fit = ops.lowrank_fit(E, Et, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
-                              cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
-        U, Ut, L = fit["U"], fit["Ut"], fit["L"]
-        if U.shape[1] != r8:           # rank above the largest multiple of 8 within min(N, K)
-            raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
-        if r8 != rank:
-            U[:, rank:] = 0
-            Ut[rank:] = 0
-            L[:, rank:] = 0
-        return U, Ut, L, fit["info"]
-    # orthonormal basis of the outlier columns (each normalised first: their norms differ by orders of
-    # magnitude).  The index list is padded to a multiple of 8; the padding columns are zeroed, and a zero
-    # column stays zero through Newton-Schulz steps, so the basis spans the real outlier columns only.
-    EO = torch.index_select(E, 1, cols).float()
-    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
-    EO[:, t:] = 0
-    EO = EO.to(torch.bfloat16).contiguous()
-    # the normalised columns are close to orthogonal already (random directions in N dimensions): two
-    # quintic and three cubic Newton-Schulz steps bring them to an orthonormal basis of the same span
-    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
-    UO[:, t:] = 0
-    UOt[t:] = 0
-    # C = Q_O^T E  [t, K] and its transpose; E' = E - Q_O C.  The outlier columns of E' are not zeroed: they
-    # hold what bf16 rounding of Q_O and C left of those columns, which the fit below can still pick up.
-    _, C, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
-    E2 = ops.lowrank_residual(UO, Ct, E, None)
-    del C
-    rf = _round_up8(rank - t)
-    over = max(FIT_MIN_OVERSAMPLE, rf // FIT_OVERSAMPLE_DIV)
-    fit = ops.lowrank_fit(E2, ops.transpose(E2), rf, over, FIT_ITERS, seed=FIT_SEED, s=s,
-                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
-    LO = ops.scale_rows(Ct, s) if s is not None else Ct
-    U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
-    L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
-    U[:, :t] = UO[:, :t]
-    U[:, t:rank] = fit["U"][:, :rank - t]
-    L[:, :t] = LO[:, :t]
-    L[:, t:rank] = fit["L"][:, :rank - t]
-    info = torch.cat([info_o, fit["info"]])
-    return U, ops.transpose(U), L, info
+    rf, over, l, t = fit_plan(N, K, rank, outliers)
+    if t == 0 and rf != _round_up8(rank):           # rank above the largest multiple of 8 within min(N, K)
+        raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+    UO = Ct = info_o = None
+    if t:
+        E, UO, Ct, info_o = deflate_outliers(E, Et, outliers)
+        Et = ops.transpose(E)
+    fit = ops.lowrank_fit(E, Et, rf, over, FIT_ITERS, seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
+                          ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
+                          sketch_split=FIT_SKETCH_SPLIT)
+    return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
 
 
 def _fit_kwargs(spread, sketch_split=True):
@@ -148,25 +157,13 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
     fit_error_matrix_back completes."""
     N, K = E.shape
     rf, over, l, t = fit_plan(N, K, rank, outliers)
-    p = dict(N=N, K=K, rank=rank, t=t, E=E)
-    if t == 0:
-        if rf != _round_up8(rank):
-            raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
-        p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
-        return p
-    cols = outliers[0]
-    EO = torch.index_select(E, 1, cols).float()
-    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
-    EO[:, t:] = 0
-    EO = EO.to(torch.bfloat16).contiguous()
-    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
-    UO[:, t:] = 0
-    UOt[t:] = 0
-    _, C, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
-    E2 = ops.lowrank_residual(UO, Ct, E, None)
-    del C
-    p.update(UO=UO, Ct=Ct, info_o=info_o, E2=E2)
-    p["ctx"] = ops.lowrank_fit_front(E2, ops.transpose(E2), rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
+    if t == 0 and rf != _round_up8(rank):
+        raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+    p = dict(N=N, K=K, rank=rank, t=t, UO=None, Ct=None, info_o=None)
+    if t:
+        E, p["UO"], p["Ct"], p["info_o"] = deflate_outliers(E, Et, outliers)
+        Et = ops.transpose(E)
+    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
     return p
 
 
@@ -180,30 +177,16 @@ def fit_error_matrix_front_group(Es, Ets, rank, outliers, spread, M_out, E_group
     rf, over, l, t = fit_plan(N, K, rank, outliers[0])
     if any(fit_plan(N, K, rank, o)[3] != t for o in outliers):
         raise ValueError("the layers of a group must deflate the same number of outlier columns")
-    p = dict(N=N, K=K, rank=rank, t=t, B=B, Es=Es)
+    if t == 0 and rf != _round_up8(rank):
+        raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+    p = dict(N=N, K=K, rank=rank, t=t, B=B, UO=[None] * B, Ct=[None] * B, info_o=[None] * B)
     if t == 0:
-        if rf != _round_up8(rank):
-            raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
         if any(Es[b].data_ptr() != E_group[b].data_ptr() or Ets[b].data_ptr() != Et_group[b].data_ptr() for b in range(B)):
             raise ValueError("without deflation the error matrices must sit in the group's strided buffers")
     else:
-        p["UO"], p["Ct"], p["info_o"] = [], [], []
         for b in range(B):
-            cols = outliers[b][0]
-            EO = torch.index_select(Es[b], 1, cols).float()
-            EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
-            EO[:, t:] = 0
-            EO = EO.to(torch.bfloat16).contiguous()
-            UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
-            UO[:, t:] = 0
-            UOt[t:] = 0
-            _, C, Ct = ops.gemm_nt(UOt, Ets[b], out_bf16=True, out_t=True)
-            ops.lowrank_residual(UO, Ct, Es[b], None, out=E_group[b])
+            _, p["UO"][b], p["Ct"][b], p["info_o"][b] = deflate_outliers(Es[b], Ets[b], outliers[b], out=E_group[b])
             ops.transpose(E_group[b], out=Et_group[b])
-            del C
-            p["UO"].append(UO)
-            p["Ct"].append(Ct)
-            p["info_o"].append(info_o)
     p["ctx"] = ops.lowrank_fit_front(E_group, Et_group, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
     return p
 
@@ -211,55 +194,18 @@ def fit_error_matrix_front_group(Es, Ets, rank, outliers, spread, M_out, E_group
 def fit_error_matrix_back_group(p, d, e, Q, vecs, ss, tail_info=None):
     """Second half for a group: d, e [B, l], Q, vecs [B, l, l]; ss = per-layer scale vectors (or None).  Returns one
     (U, Ut, L, info) per layer, as fit_error_matrix_back does.  tail_info: see ops.lowrank_fit_back."""
-    N, K, rank, t, B = p["N"], p["K"], p["rank"], p["t"], p["B"]
-    r8 = _round_up8(rank)
     s = torch.stack(ss).contiguous() if ss is not None else None
     fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s, tail_info=tail_info)
-    out = []
-    for b in range(B):
-        if t == 0:
-            U, Ut, L = fit["U"][b], fit["Ut"][b], fit["L"][b]
-            if r8 != rank:
-                U[:, rank:] = 0
-                Ut[rank:] = 0
-                L[:, rank:] = 0
-            out.append((U, Ut, L, fit["info"][b]))
-            continue
-        E = p["Es"][b]
-        LO = ops.scale_rows(p["Ct"][b], ss[b]) if ss is not None else p["Ct"][b]
-        U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
-        L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
-        U[:, :t] = p["UO"][b][:, :t]
-        U[:, t:rank] = fit["U"][b][:, :rank - t]
-        L[:, :t] = LO[:, :t]
-        L[:, t:rank] = fit["L"][b][:, :rank - t]
-        out.append((U, ops.transpose(U), L, torch.cat([p["info_o"][b], fit["info"][b]])))
-    return out
+    return [_assemble(p["N"], p["K"], p["rank"], p["t"], ss[b] if ss is not None else None, fit["U"][b], fit["Ut"][b],
+                      fit["L"][b], fit["info"][b], p["UO"][b], p["Ct"][b], p["info_o"][b]) for b in range(p["B"])]
 
 
 def fit_error_matrix_back(p, d, e, Q, vecs, s, tail_info=None):
     """Second half of fit_error_matrix: (d, e, Q) = the tridiagonalised Rayleigh-Ritz matrix of this layer; returns what
     fit_error_matrix returns, from the same arithmetic."""
-    N, K, rank, t = p["N"], p["K"], p["rank"], p["t"]
-    r8 = _round_up8(rank)
     fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s, tail_info=tail_info)
-    if t == 0:
-        U, Ut, L = fit["U"], fit["Ut"], fit["L"]
-        if r8 != rank:
-            U[:, rank:] = 0
-            Ut[rank:] = 0
-            L[:, rank:] = 0
-        return U, Ut, L, fit["info"]
-    E = p["E"]
-    LO = ops.scale_rows(p["Ct"], s) if s is not None else p["Ct"]
-    U = torch.zeros(N, r8, dtype=E.dtype, device=E.device)
-    L = torch.zeros(K, r8, dtype=E.dtype, device=E.device)
-    U[:, :t] = p["UO"][:, :t]
-    U[:, t:rank] = fit["U"][:, :rank - t]
-    L[:, :t] = LO[:, :t]
-    L[:, t:rank] = fit["L"][:, :rank - t]
-    info = torch.cat([p["info_o"], fit["info"]])
-    return U, ops.transpose(U), L, info
+    return _assemble(p["N"], p["K"], p["rank"], p["t"], s, fit["U"], fit["Ut"], fit["L"], fit["info"], p["UO"], p["Ct"],
+                     p["info_o"])
 
 
 def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, rank=None):
@@ -339,10 +285,6 @@ class LoraContext:
         st = torch.cuda.current_stream()
         for t in self.tensors():
             t.record_stream(st)
-
-    def group_key(self):
-        """Layers with equal keys can be fitted in lockstep by one batched call."""
-        return (tuple(self.W.shape), self.rank, self.s is not None, self.outliers is None)
 
 
 # Adam iterations of the adapter re-fit after pruning (the reference's default, lora.py:11)
@@ -425,14 +367,6 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     return c
 
 
-def planned_group_key(module, rank_ratio, lora_tile_size, slim_lora, activations):
-    """LoraContext.group_key() of a layer before it is prepared (needs activations.has_zero / .outliers)."""
-    N, K = module.weight.shape
-    rank = min(lora_rank((N, K), rank_ratio, lora_tile_size), min(N, K))
-    use_slim = bool(slim_lora) and not activations.has_zero
-    return ((N, K), rank, use_slim, (not use_slim) or activations.outliers is None)
-
-
 def planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations):
     """Size of the eigenproblem add_lora's fit will pose for this layer (needs activations.has_zero / .outliers), or None
     when the shared eigen-solver does not take it."""
@@ -495,44 +429,21 @@ def add_lora_fit_back(c, d, e, Q, vecs, tail_info=None):
     c.pending = None
 
 
-def add_lora_fit(ctxs, E_group=None, Et_group=None):
-    """Second phase: the low-rank fit (lora.py:172-195).  Contexts whose E / Et are the slices, in order, of
-    E_group [B, N, K] / Et_group [B, K, N] are fitted in lockstep by one batched call; otherwise one by one."""
-    if E_group is None or len(ctxs) == 1:
-        for c in ctxs:
-            c.touch()
-            # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row); pruned
-            # adapters are pruned and re-fitted before that division (lora.py:185-195)
-            scaled_in_fit = c.separate and not c.prune_lora
-            c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread)
-            if c.prune_lora:
-                U, Ut, L, info = c.fit
-                c.lora_left_mask = prune_and_optimize_lora(L, Ut, PRUNE_LORA_ITERS)
-                U = ops.transpose(Ut)
-                if c.s is not None:
-                    ops.scale_rows(L, c.s)
-                c.fit = (U, Ut, L, info)
-        return
-    assert len({c.group_key() for c in ctxs}) == 1 and ctxs[0].outliers is None and E_group.shape[0] == len(ctxs)
-    assert all(c.separate for c in ctxs), "merged adapters are fitted one by one"
+def add_lora_fit(ctxs):
+    """Second phase: the low-rank fit (lora.py:172-195), one context after the other."""
     for c in ctxs:
         c.touch()
-    rank = ctxs[0].rank
-    r8 = _round_up8(rank)
-    N, K = ctxs[0].W.shape
-    over = max(FIT_MIN_OVERSAMPLE, r8 // FIT_OVERSAMPLE_DIV)
-    s = torch.stack([c.s for c in ctxs]).contiguous() if ctxs[0].s is not None else None
-    fit = ops.lowrank_fit(E_group, Et_group, min(r8, min(N, K) - min(N, K) % 8), over, FIT_ITERS, seed=FIT_SEED, s=s,
-                          cholesky_qr=FIT_CHOLESKY_QR, ns_steps=max(fit_ns_steps(c.spread) for c in ctxs), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL, sketch_split=FIT_SKETCH_SPLIT)
-    U, Ut, L = fit["U"], fit["Ut"], fit["L"]
-    if U.shape[-1] != r8:
-        raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
-    if r8 != rank:
-        U[..., rank:] = 0
-        Ut[:, rank:] = 0
-        L[..., rank:] = 0
-    for b, c in enumerate(ctxs):
-        c.fit = (U[b], Ut[b], L[b], fit["info"][b])
+        # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row); pruned
+        # adapters are pruned and re-fitted before that division (lora.py:185-195)
+        scaled_in_fit = c.separate and not c.prune_lora
+        c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread)
+        if c.prune_lora:
+            U, Ut, L, info = c.fit
+            c.lora_left_mask = prune_and_optimize_lora(L, Ut, PRUNE_LORA_ITERS)
+            U = ops.transpose(Ut)
+            if c.s is not None:
+                ops.scale_rows(L, c.s)
+            c.fit = (U, Ut, L, info)
 
 
 def add_lora_finish(c):

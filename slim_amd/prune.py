@@ -35,20 +35,12 @@ STATS_CALLBACK = None
 # phases of the other linears.  Each stream is fed by its own host thread (run_on_streams); 7 = one per linear
 # of a LLaMA block.  1 = everything on the current stream.
 COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "7"))
-# Fit same-shape linears of a block (q/k/v/o, gate/up) in lockstep with one batched call.  Off by default: the
-# batched eigen-solver of rocSOLVER takes as long as the single ones one after the other, and separate fits
-# overlap their solver chains on different streams, which is faster as long as that solver is on the path.
-BATCH_FITS = os.environ.get("SLIM_BATCH_FITS", "0") == "1"
 # the eigenproblems of a block's fits share one batched tridiagonalisation chain (SLIM_SHARED_EIGH=0: every fit solves its own)
 SHARED_EIGH = os.environ.get("SLIM_SHARED_EIGH", "1") == "1"
 # with the shared eigen-solver: linears of a block with the same shape and input statistics (q/k/v, gate/up) run their fits
 # as one lockstep chain (SLIM_GROUP_FITS=0: one chain per linear)
 GROUP_FITS = os.environ.get("SLIM_GROUP_FITS", "1") == "1"
 GROUP_MAX = int(os.environ.get("SLIM_GROUP_MAX", "0"))
-# with lockstep groups: prepare all linears (mask, first scale search, error matrix) in a phase of their own instead of
-# at the head of their group's chain (measured slower, 44.6 vs 42.6 ms per block: the phase's barrier costs more than the
-# serial prepares of a chain, so it is off)
-PREPARE_PHASE = os.environ.get("SLIM_PREPARE_PHASE", "0") == "1"
 # which of the side streams carry the chains when there are at most that many: HIP spreads a process's streams over four
 # in-order hardware queues, and these four of the seven side streams sit on four different ones
 GROUP_STREAM_IDS = [int(x) for x in os.environ.get("SLIM_GROUP_STREAMS", "0,1,2,6").split(",") if x != ""]
@@ -311,12 +303,13 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
     """Compress the linears of one block after their statistics pass (the body of the per-linear loop of
     prune.py:256-357).  items: list of (name, nn.Linear, WrappedGPT) with block_stats() already applied.
 
-    With adapters the work runs in three phases, each spread over the side streams: (1) per linear: mask,
-    first scale search, error matrix; (2) per group of same-shape linears (q/k/v/o, gate/up): ONE batched
-    low-rank fit, so the launch count and the eigen-solve chain are paid once per group; (3) per linear:
-    residual weight, second scale search, re-quantisation, adapter attributes and hook.
+    With adapters the work runs in phases, each spread over the side streams: (1) per group of linears with the same
+    shape and input statistics (q/k/v, gate/up): mask, first scale search, error matrix and the low-rank fit up to its
+    l x l Rayleigh-Ritz matrix, as one lockstep chain; (2) ONE batched eigen-solver chain per eigenproblem size for the
+    whole block; (3) per group: the factors; (4) per linear: residual weight, second scale search, re-quantisation,
+    adapter attributes and hook.
     shard=True (several ranks, every rank passing the same items): the row-block partition of sharded.py instead."""
-    from .lora import (add_lora_prepare, add_lora_fit, add_lora_finish, planned_group_key)
+    from .lora import add_lora_prepare, add_lora_fit, add_lora_finish
     if shard:
         # every rank holds a block of every linear (the caller has checked sharded.supported on these items)
         from . import sharded
@@ -364,41 +357,18 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
         return
 
     tile = lora_tile_size if (quantize_lora or pad_lora) else None
-    # groups of linears whose fits can run in lockstep, with one strided E / E^T buffer per group
-    groups = {}
-    for idx, (name, lin, wrapped) in enumerate(items):
+    for _, _, wrapped in items:
         if getattr(wrapped, "has_zero", None) is None:
             block_stats([wrapped])
-        groups.setdefault(planned_group_key(lin, lora_rank, tile, slim_lora, wrapped), []).append(idx)
-    slot, buffers = {}, {}
-    for key, members in groups.items():
-        (N, K), _, _, batchable = key
-        if BATCH_FITS and separate_lora and batchable and not prune_lora and len(members) > 1:
-            buffers[key] = (torch.empty(len(members), N, K, dtype=torch.bfloat16, device=dev),
-                            torch.empty(len(members), K, N, dtype=torch.bfloat16, device=dev))
-            for b, idx in enumerate(members):
-                slot[idx] = (key, b)
     ctxs = [None] * len(items)
 
     def prepare(idx):
         name, lin, wrapped = items[idx]
         if describe:
             describe(name)
-        E_out = Et_out = None
-        if idx in slot:
-            key, b = slot[idx]
-            E_out, Et_out = buffers[key][0][b], buffers[key][1][b]
-        c = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
-                             separate_lora, tile, quantize_first, scale_important_weights, E_out, Et_out)
-        ctxs[idx] = c
-        return c.tensors()
-
-    def fit(key, members):
-        if key in buffers:
-            add_lora_fit([ctxs[i] for i in members], *buffers[key])
-        else:
-            add_lora_fit([ctxs[i] for i in members])
-        return [t for i in members for t in ctxs[i].tensors()]
+        ctxs[idx] = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
+                                     separate_lora, tile, quantize_first, scale_important_weights)
+        return ctxs[idx].tensors()
 
     def finish(idx):
         name, lin, wrapped = items[idx]
@@ -415,7 +385,7 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
         ctxs[idx] = None
         return produced(lin)
 
-    if not buffers and SHARED_EIGH and separate_lora and not prune_lora and len(items) > 1:
+    if SHARED_EIGH and separate_lora and not prune_lora and len(items) > 1:
         # The fits of a block pose one l x l eigenproblem each, and its first stage (Householder tridiagonalisation) is a
         # chain of l dependent launches: seven chains side by side take seven times the launches on four in-order
         # hardware queues.  So the linears run to their Rayleigh-Ritz matrix on the side streams, ONE batched chain
@@ -464,14 +434,12 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                 members = fit_groups[g][1]
                 l, b0 = where[g]
                 if gbuf[g] is None:
-                    if not PREPARE_PHASE:
-                        prepare_member(g, 0)
+                    prepare_member(g, 0)
                     _lora.add_lora_fit_front(ctxs[members[0]], Mb[l][b0], sketch_split=split)
                 else:
                     Eg, Etg, t = gbuf[g]
-                    if not PREPARE_PHASE:
-                        for b in range(len(members)):
-                            prepare_member(g, b)
+                    for b in range(len(members)):
+                        prepare_member(g, b)
                     _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], Eg, Etg,
                                                    sketch_split=split)
                 return [x for i in members for x in ctxs[i].tensors()] + ([gbuf[g][0], gbuf[g][1]] if gbuf[g] else [])
@@ -490,9 +458,6 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
             # (splitting the linears into two groups so that one group's chain overlaps the other's GEMM-heavy halves was
             # measured slower, 56.7 vs 47 ms: the extra barriers cost more than the idle chip during the shared chain)
             ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
-            if PREPARE_PHASE:       # mask, scale search and error matrix of every linear side by side, off the chains
-                run_on_streams([lambda g=g, b=b: prepare_member(g, b) for g in range(len(fit_groups))
-                                for b in range(len(fit_groups[g][1]))], dev, n_streams)
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             # the eigenproblems of the block, size by size: one tridiagonalisation chain and three launches for the
             # tridiagonal stage, each carrying every problem of that size
@@ -505,26 +470,13 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
             run_on_streams([lambda g=g: back(g, tri) for g in range(len(fit_groups))], dev, n_streams, ids)
             run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
             return
-    if not buffers:
-        # nothing to fit in lockstep: the three phases of a linear run back to back on one stream, so the
-        # linears overlap freely (no barrier between the phases)
-        def whole(idx):
-            prepare(idx)
-            add_lora_fit([ctxs[idx]])
-            return finish(idx)
-        run_on_streams([lambda i=i: whole(i) for i in range(len(items))], dev, n_streams)
-        return
-    run_on_streams([lambda i=i: prepare(i) for i in range(len(items))], dev, n_streams)
-    # a group that cannot be batched (outlier deflation, a single member) is fitted member by member, each
-    # member as a job of its own
-    fit_jobs = []
-    for key, members in groups.items():
-        if key in buffers:
-            fit_jobs.append(lambda key=key, members=members: fit(key, members))
-        else:
-            fit_jobs += [lambda key=key, i=i: fit(key, [i]) for i in members]
-    run_on_streams(fit_jobs, dev, n_streams)
-    run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
+    # a single linear, pruned or merged adapters, or an eigenproblem the shared solver does not take: the three phases of a
+    # linear run back to back on one stream, and the linears overlap freely
+    def whole(idx):
+        prepare(idx)
+        add_lora_fit([ctxs[idx]])
+        return finish(idx)
+    run_on_streams([lambda i=i: whole(i) for i in range(len(items))], dev, n_streams)
 
 
 def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale, separate_lora=True,
