@@ -306,6 +306,16 @@ int slim_gramfit_factors(int right, const void* P, const void* Z, int64_t Dm, in
  * N x K low-rank product itself) is written too when non-NULL; mask may be NULL (nothing zeroed). */
 int slim_lowrank_residual(const void* U, const void* L, int N, int K, int r, const void* W_bf16,
                           const uint8_t* mask, void* Wn_bf16, void* LR_bf16, void* stream);
+/* The tail of add_lora, slim/lora.py:199-209, with the pre-scaling of the adapters of slim/prune.py:296-301, for separate
+ * adapters and a per-tensor quantiser, in one call: Wn = mask ? 0 : bf16(W - bf16(U L^T)) (U [N, r8], L [K, r8], columns
+ * >= rank zero); sf = the scale of Wn (quant_mode 1: SLiM-Quant search with max(512, min(N K / 1000, 20000)) bins,
+ * quantization.py:187; 2: abs-max; 0: no quantiser, sf_out untouched); W_out = deq(quant(Wn, sf)) in bf16;
+ * lora_left_out [K, rank] = L[:, :rank] * c, lora_right_out [rank, N] = U[:, :rank]^T * c, c = sqrt(rank) when prescale != 0
+ * (what the driver stores, prune.py:298-300), else 1 (what add_lora itself leaves). */
+int64_t slim_lora_finish_workspace_bytes(int64_t N, int64_t K);
+int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t K, int r8, int rank, const void* W_bf16,
+                     const uint8_t* mask, int quant_mode, int num_bits, int prescale, void* W_out_bf16, float* sf_out,
+                     void* lora_left_out, void* lora_right_out, void* workspace, int64_t workspace_bytes, void* stream);
 /* Same subtraction from a materialised LR, optionally accumulating the |bf16| histogram of Wn. */
 int slim_residual_weight(const void* W_bf16, const void* LR_bf16, const uint8_t* mask, int64_t numel, void* Wn_bf16,
                          uint32_t* hist, void* stream);

@@ -72,6 +72,8 @@ PROTOTYPES = {
     "slim_gramfit_iterate": (i32, [vp, i64, i32, i32, u32, i32, i32, vp, vp, vp, vp, i64, vp]),
     "slim_gramfit_project": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, vp, i64, vp]),
     "slim_gramfit_factors": (i32, [i32, vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp]),
+    "slim_lora_finish_workspace_bytes": (i64, [i64, i64]),
+    "slim_lora_finish": (i32, [vp, vp, i64, i64, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_residual": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "slim_residual_weight": (i32, [vp, vp, vp, i64, vp, vp, vp]),
     "slim_randn_bf16": (i32, [vp, i64, u32, vp]),

@@ -953,6 +953,76 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
 }
 
 
+// ---- the tail of add_lora in one call ------------------------------------------------------------------------------------
+// out[k][j] = bf16(float(in[k][j]) * scale) for j < cols_out: a [rows, ld_in] factor cut to its first cols_out columns
+__global__ void scale_cut_kernel(const bf16_t* __restrict__ in, int64_t rows, int64_t ld_in, int64_t cols_out, float scale,
+                                 bf16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols_out) return;
+    const int64_t k = i / cols_out, j = i - k * cols_out;
+    out[i] = f32_to_bf16(bf16_to_f32(in[k * ld_in + j]) * scale);
+}
+
+// out[j][n] = bf16(float(in[n][j]) * scale) for j < rows_out: the transpose of a [N, ld_in] factor cut to rows_out rows
+__global__ __launch_bounds__(256) void scale_transpose_cut_kernel(const bf16_t* __restrict__ in, int64_t N, int64_t ld_in,
+                                                                  int64_t rows_out, float scale, bf16_t* __restrict__ out) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t n0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t n = n0 + r, j = j0 + tx;
+        tile[r][tx] = (n < N && j < rows_out) ? in[n * ld_in + j] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t j = j0 + r, n = n0 + tx;
+        if (j < rows_out && n < N) out[j * N + n] = f32_to_bf16(bf16_to_f32(tile[tx][r]) * scale);
+    }
+}
+
+extern "C" int64_t slim_lora_finish_workspace_bytes(int64_t N, int64_t K) {
+    if (N <= 0 || K <= 0) return -1;
+    const int64_t numel = N * K;
+    const int64_t bins = numel / 1000 < 512 ? 512 : (numel / 1000 > 20000 ? 20000 : numel / 1000);
+    return al256(32768 * 4) + al256(slim_quant_search_workspace_bytes((int)bins)) + 256;
+}
+
+// slim/lora.py:199-209 + slim/prune.py:296-301 for separate adapters and a per-tensor quantiser (or none), in one call:
+//   Wn = mask ? 0 : bf16(W - bf16(U L^T));  sf = scale of Wn (SLiM-Quant search, quant_mode 1; abs-max, 2; none, 0);
+//   W_out = deq(quant(Wn, sf));  lora_left_out [K, rank] = L[:, :rank] * c;  lora_right_out [rank, N] = (U[:, :rank])^T * c
+//   with c = sqrt(rank) (prescale != 0: the pre-scaling of prune.py:298-300) or 1.
+extern "C" int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t K, int r8, int rank, const void* W,
+                                const uint8_t* mask, int quant_mode, int num_bits, int prescale, void* W_out, float* sf_out,
+                                void* lora_left_out, void* lora_right_out, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+    SLIM_REQUIRE(U && L && W && mask && W_out && lora_left_out && lora_right_out && workspace, "slim_lora_finish: null pointer");
+    SLIM_REQUIRE(N > 0 && K > 0 && r8 > 0 && r8 % 8 == 0 && rank > 0 && rank <= r8 && N < (1 << 30) && K < (1 << 30),
+                 "slim_lora_finish: bad sizes");
+    SLIM_REQUIRE(quant_mode >= 0 && quant_mode <= 2 && (quant_mode == 0 || sf_out), "slim_lora_finish: bad quantiser mode");
+    SLIM_REQUIRE(workspace_bytes >= slim_lora_finish_workspace_bytes(N, K), "slim_lora_finish: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    CHK(slim_lowrank_residual(U, L, (int)N, (int)K, r8, W, mask, W_out, nullptr, stream));
+    if (quant_mode) {
+        uint32_t* hist = (uint32_t*)workspace;
+        char* search_ws = (char*)workspace + al256(32768 * 4);
+        const int64_t numel = N * K;
+        const int64_t bins = numel / 1000 < 512 ? 512 : (numel / 1000 > 20000 ? 20000 : numel / 1000);
+        const int64_t search_bytes = al256(slim_quant_search_workspace_bytes((int)bins));
+        float* alpha = (float*)(search_ws + search_bytes);
+        CHK(slim_hist_abs_bf16(W_out, numel, hist, 0, stream));
+        if (quant_mode == 1) CHK(slim_quant_search(hist, (int)bins, num_bits, alpha, nullptr, sf_out, search_ws, search_bytes, stream));
+        else CHK(slim_absmax_scale(hist, num_bits, alpha, sf_out, stream));
+        CHK(slim_fake_quant_pt(W_out, numel, sf_out, num_bits, W_out, nullptr, stream));
+    }
+    const float sq = prescale ? sqrtf((float)rank) : 1.f;
+    scale_cut_kernel<<<(unsigned)ceil_div64(K * rank, 256), 256, 0, st>>>((const bf16_t*)L, K, r8, rank, sq, (bf16_t*)lora_left_out);
+    SLIM_LAUNCH_CHECK();
+    const dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)ceil_div64(rank, 64));
+    scale_transpose_cut_kernel<<<grid, 256, 0, st>>>((const bf16_t*)U, N, r8, rank, sq, (bf16_t*)lora_right_out);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 // ---- the pieces of the Gram-side fit as separate calls -----------------------------------------------------------------
 // For a layer sharded over several GPUs along its long dimension: every GPU forms the Gram matrix of its shard of E
 // (slim_gemm_nt_bf16 with fp32 output), the sum over the shards goes to one GPU, which runs the subspace iteration

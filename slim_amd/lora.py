@@ -9,12 +9,13 @@ from . import ops
 from .quantization.quantization import Quantizer as AutoQuantizer
 from .utils import get_layers_list, find_layers
 
-# Randomized-fit parameters: subspace dimension l = rank + max(FIT_MIN_OVERSAMPLE, rank // 4), and the
-# number of subspace iterations.  SLiM error matrices have a flat spectrum (sigma_r / sigma_(r+128) = 1.04 - 1.06 on
-# LLaMA-2-7B-shaped layers), so the excess over the truncated SVD only halves per iteration: measured on
-# 4096 x 11008 with rank 512 (tools/fit_accuracy.py) 1.6e-3 after 6, 4.7e-4 after 8, < 1e-5 after 10
-# iterations, against a budget of 1e-3; an iteration costs ~0.7 ms of a ~20 ms fit.
-FIT_OVERSAMPLE_DIV = 4
+# Randomized-fit parameters: subspace dimension l = rank + max(FIT_MIN_OVERSAMPLE, rank // FIT_OVERSAMPLE_DIV), and the
+# number of subspace iterations.  SLiM error matrices have a flat spectrum (sigma_r / sigma_(r+128) = 1.03 - 1.06 on
+# LLaMA-2-7B / 13B-shaped layers), so the excess over the truncated SVD only halves per iteration: measured on
+# 4096 x 11008 with rank 512 (tests/test_fullsize_gpu.py, tools/fit_accuracy.py) 2e-3 after 6 iterations, 3.4e-4 after
+# 10 with 64 extra columns and -6e-5 with 128, against a budget of 1e-3.  64 extra columns (rank // 8 at rank 512) are
+# taken: every product, orthonormalisation and the l-launch chain of the eigen-solver scale with l (one fit 10.4 -> 9.2 ms).
+FIT_OVERSAMPLE_DIV = 8
 FIT_MIN_OVERSAMPLE = 64
 FIT_ITERS = 10
 FIT_SEED = 0
@@ -446,13 +447,30 @@ def add_lora_fit(ctxs):
             c.fit = (U, Ut, L, info)
 
 
-def add_lora_finish(c):
+def add_lora_finish(c, prescale=False):
     """Third phase (lora.py:199-209): residual weight W - R^T L^T, masked, second quantisation; sets
     module.lora_left [K, r], module.lora_right [r, N], module.weight.data.  Returns the second scaling
-    factor (fp32 (1, 1)) or None; it is also left in quantizer.scaling_factor like the reference does."""
+    factor (fp32 (1, 1)) or None; it is also left in quantizer.scaling_factor like the reference does.
+    prescale=True (the driver, slim/prune.py:296-301): the adapters are stored multiplied by sqrt(rank) and
+    module.lora_rank is set."""
     c.touch()
     U, lora_right, lora_left, fit_info = c.fit
     module, quantizer, rank = c.module, c.quantizer, c.rank
+    if c.separate and c.lora_left_mask is None and (quantizer is None or not quantizer.block_quantization):
+        # separate adapters, per-tensor quantiser or none: the whole tail is one library call
+        mode = 0 if quantizer is None else (1 if quantizer.slim_quant else 2)
+        new_weight, sf, left, right = ops.lora_finish(U, lora_left, c.W, c.W_mask, rank, mode, c.bits, prescale)
+        sf_out = None
+        if quantizer is not None:
+            sf_out = (sf if quantizer.slim_quant else sf.to(torch.bfloat16)).reshape(1, 1)
+            quantizer.scaling_factor = sf_out
+        module.lora_fit_info = fit_info
+        module.lora_left = torch.nn.Parameter(left)
+        module.lora_right = torch.nn.Parameter(right)
+        module.weight.data = new_weight
+        if prescale:
+            module.lora_rank = torch.tensor(rank)
+        return sf_out
     low_rank_weight = None
     if c.separate:
         new_weight = ops.lowrank_residual(U, lora_left, c.W, c.W_mask)
@@ -483,6 +501,10 @@ def add_lora_finish(c):
     module.weight.data = new_weight.to(torch.bfloat16).contiguous()
     if c.lora_left_mask is not None:
         module.lora_left_mask = c.lora_left_mask[:, :rank].contiguous()              # lora.py:210-211
+    if prescale:
+        module.lora_rank = torch.tensor(module.lora_left.shape[1])
+        module.lora_left = torch.nn.Parameter(module.lora_left * torch.sqrt(module.lora_rank))
+        module.lora_right = torch.nn.Parameter(module.lora_right * torch.sqrt(module.lora_rank))
     return sf_out
 
 

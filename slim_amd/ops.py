@@ -541,6 +541,26 @@ def lowrank_residual(U, L, W, mask, want_lr=False, out=None):
     return (Wn, LR) if want_lr else Wn
 
 
+def lora_finish(U, L, W, mask, rank, quant_mode, num_bits, prescale):
+    """The tail of add_lora in one call (slim_lora_finish): returns (compressed weight bf16 [N, K], scaling factor fp32 [1]
+    or None, lora_left [K, rank], lora_right [rank, N]).  quant_mode: 0 none, 1 SLiM-Quant, 2 abs-max."""
+    U = _chk(U, BF16, "U")
+    L = _chk(L, BF16, "L")
+    W = _chk(W, BF16, "W")
+    mask = _chk(mask, torch.bool, "mask")
+    N, K = W.shape
+    r8 = U.shape[1]
+    dev = W.device
+    Wq = torch.empty_like(W)
+    sf = torch.empty(1, dtype=torch.float32, device=dev) if quant_mode else None
+    left = torch.empty(K, rank, dtype=BF16, device=dev)
+    right = torch.empty(rank, N, dtype=BF16, device=dev)
+    ws = _ws(_lib.query("slim_lora_finish_workspace_bytes", N, K), dev)
+    _lib.call("slim_lora_finish", _p(U), _p(L), N, K, r8, int(rank), _p(W), _p(mask), int(quant_mode), int(num_bits), int(bool(prescale)),
+              _p(Wq), _p(sf), _p(left), _p(right), _p(ws), ws.numel(), _stream())
+    return Wq, sf, left, right
+
+
 def residual_weight(W, LR, mask, want_hist=False):
     W = _chk(W, BF16, "W")
     LR = _chk(LR, BF16, "LR")

@@ -372,13 +372,10 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
 
     def finish(idx):
         name, lin, wrapped = items[idx]
-        sf = add_lora_finish(ctxs[idx])
+        sf = add_lora_finish(ctxs[idx], prescale=separate_lora)       # prune.py:296-301: adapters stored times sqrt(rank)
         if quantizer is not None:
             lin.scaling_factor = None if tiled_weight_quantization else sf
         if separate_lora:
-            lin.lora_rank = torch.tensor(lin.lora_left.shape[1])
-            lin.lora_left = torch.nn.Parameter(lin.lora_left * torch.sqrt(lin.lora_rank))
-            lin.lora_right = torch.nn.Parameter(lin.lora_right * torch.sqrt(lin.lora_rank))
             lin.register_forward_hook(add_lora_hook)
         if callback is not None:
             callback(name, lin, wrapped)
