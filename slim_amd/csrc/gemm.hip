@@ -590,27 +590,78 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
     gemm_stamp(g, 3);
 }
 
-// C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n, int N, float alpha, float beta,
-                                     float* __restrict__ C32, int64_t ldc32, bf16_t* __restrict__ C16, int64_t ldc16,
-                                     int64_t sSlab, int64_t sC32, int64_t sC16, int sym_tile, float c16_diag) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t bz = blockIdx.y;          // strided batch
+// C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order.  One 64 x 64 tile per
+// workgroup, read as 16-byte pieces of every slice.  Symmetric products fill only the 128 x 128 tiles on and above the
+// diagonal: the workgroups of the tiles below it leave at once, those above it write their tile and, through LDS, its
+// transpose into the mirrored position (bit-identical to summing the mirrored slab entries: the same numbers in the
+// same order).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N, float alpha,
+                                                            float beta, float* __restrict__ C32, int64_t ldc32,
+                                                            bf16_t* __restrict__ C16, int64_t ldc16, int64_t sSlab, int64_t sC32,
+                                                            int64_t sC16, int sym_tile, float c16_diag) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const int64_t bz = blockIdx.z;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const bool mirror = sym_tile && row0 / sym_tile < col0 / sym_tile;
+    if (sym_tile && row0 / sym_tile > col0 / sym_tile) return;
     slab += bz * sSlab;
     if (C32) C32 += bz * sC32;
     if (C16) C16 += bz * sC16;
-    const int64_t row = i / N, col = i - row * N;
-    // symmetric products fill only the tiles on and above the diagonal: below it, read the mirrored element
-    const int64_t src = (sym_tile && row / sym_tile > col / sym_tile) ? col * N + row : i;
-    float acc = 0.f;
-    for (int z = 0; z < splits; ++z) acc += slab[(int64_t)z * n + src];
-    float v = acc * alpha;
-    if (C32) {
-        if (beta != 0.f) v += beta * C32[row * ldc32 + col];
-        C32[row * ldc32 + col] = v;
+    const int64_t n = (int64_t)M * N;
+    const int tx = (t & 15) * 4, ty = t >> 4;
+    const bool vec = (N & 3) == 0 && ((uintptr_t)slab & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 16 * i, row = row0 + r, col = col0 + tx;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < M && col < N) {
+            const float* p = slab + (int64_t)row * N + col;
+            if (vec && col + 3 < N) {
+                for (int z = 0; z < splits; ++z) {
+                    const f32x4 q = *(const f32x4*)(p + (int64_t)z * n);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] += q[u];
+                }
+            } else {
+                for (int z = 0; z < splits; ++z)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (col + u < N) v[u] += p[(int64_t)z * n + u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] *= alpha;
+            if (row < M && col + u < N) {
+                if (C32) {
+                    if (beta != 0.f) v[u] += beta * C32[(int64_t)row * ldc32 + col + u];
+                    C32[(int64_t)row * ldc32 + col + u] = v[u];
+                }
+                if (C16) C16[(int64_t)row * ldc16 + col + u] = f32_to_bf16(row == col + u ? v[u] - c16_diag : v[u]);
+            }
+            tile[r][tx + u] = v[u];
+        }
     }
-    if (C16) C16[row * ldc16 + col] = f32_to_bf16(row == col ? v - c16_diag : v);
+    if (!mirror) return;
+    __syncthreads();
+    // the transposed tile: element (col0 + c, row0 + r) = tile[r][c]; strictly off the diagonal, so no diagonal shift
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = ty + 16 * i, mrow = col0 + c;          // row of the mirrored position
+        if (mrow >= N) continue;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mcol = row0 + tx + u;
+            if (mcol >= M) continue;
+            float v = tile[tx + u][c];
+            if (C32) {
+                if (beta != 0.f) v += beta * C32[(int64_t)mrow * ldc32 + mcol];
+                C32[(int64_t)mrow * ldc32 + mcol] = v;
+            }
+            if (C16) C16[(int64_t)mrow * ldc16 + mcol] = f32_to_bf16(v);
+        }
+    }
 }
 
 // The same reduction for products that also want the transposed bf16 output (the sketch products of the fit): a
@@ -800,9 +851,9 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
             SLIM_LAUNCH_CHECK();
             return SLIM_OK;
         }
-        const int64_t n = (int64_t)g.M * g.N;
-        dim3 rgrid((unsigned)ceil_div64(n, 256), (unsigned)batch);
-        splitk_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, n, g.N, g.alpha, g.beta, g.C32, g.ldc32,
+        dim3 rgrid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)batch);
+        SLIM_REQUIRE(rgrid.y <= 65535, "slim_gemm_nt_bf16: too many rows for the split-K reduction");
+        splitk_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)stream>>>(g.slab, g.splits, g.M, g.N, g.alpha, g.beta, g.C32, g.ldc32,
                                                                      g.C16, g.ldc16, g.sSlab, g.sC32, g.sC16, g.sym ? BM : 0, g.c16_diag);
         SLIM_LAUNCH_CHECK();
         return SLIM_OK;

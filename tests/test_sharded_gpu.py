@@ -169,3 +169,45 @@ def test_block_stages_are_bit_exact():
                 assert torch.equal(ops.quantize_pt(Ws, sf, 4), codes[sl])
                 assert torch.equal(ops.error_matrix(Ws, ms, ss, sf, 4)[1], E[sl])
             assert torch.equal(acc, hist)
+
+
+def test_sharded_code_path_at_13b_shape_within_1e3_of_truncated_svd():
+    """The pieces of the sharded fit (Gram contribution, slim_gramfit_iterate / project / factors, batched eigen-solver) on a
+    LLaMA-2-13B-shaped linear (5120 x 13824, rank 512, column blocks): the adapters' fit error against the exact truncated
+    SVD of the error matrix (slim/lora.py:172-185), budget 1e-3 as for the single-GPU path.  One rank, so no exchange; the
+    two-rank run of the same code is the test above."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slim_amd import ops, sharded
+    from slim_amd.prune import block_stats
+    from slim_amd.layerwrapper import WrappedGPT
+    from slim_amd.quantization.quantization import Quantizer
+    N, K, rank = 5120, 13824, 512
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lin = torch.nn.Linear(K, N, bias=False, device=DEV, dtype=torch.bfloat16)
+    lin.weight.requires_grad_(False)
+    lin.weight.data = (torch.randn(N, K, generator=g, device=DEV) * 0.02).to(torch.bfloat16)
+    W0 = lin.weight.data.clone()
+    scale = torch.exp(torch.randn(K, generator=g, device=DEV) * 0.5)
+    scale[torch.randperm(K, generator=g, device=DEV)[:4]] *= 30.0
+    w = WrappedGPT(lin)
+    w.scaler_row = ops.shift_zeros((scale * scale * 2048.0).float())
+    s = torch.sqrt(w.scaler_row)
+    block_stats([w], lambda w: rank)
+    q = Quantizer("weight", num_bits=4, slim_quant=True)
+    items = [("down_proj", lin, w)]
+    assert sharded.supported(items, 8, 2, 4, q, 0.1, True, False, True, True, 256)      # 108 aligned column blocks for 8 ranks
+    status = sharded.compress_linears_sharded(items, torch.device(DEV), 2, 4, q, 0.1, True, 256)
+    assert int(status.abs().sum()) == 0
+    assert int(lin.lora_rank) == rank and lin.lora_left.shape == (K, rank) and lin.lora_right.shape == (rank, N)
+    mask = ops.mask_nm(W0, s, 2, 4)
+    sf1 = ops.quant_search(ops.hist_abs(W0), 20000, 4)[2].reshape(1)
+    E32 = ops.error_matrix(W0, mask, s, sf1, 4, want_f32=True)[0]
+    approx = (lin.lora_left.data.float() @ lin.lora_right.data.float()).t() / rank * s.reshape(1, -1)
+    err = float(torch.norm(E32 - approx))
+    sv = torch.linalg.svdvals(E32)
+    opt = float(torch.sqrt((sv[rank:].double() ** 2).sum()))
+    print(f"5120x13824 sharded code path: fit error {err:.3f}, truncated SVD {opt:.3f}, excess {err / opt - 1:+.2e}, "
+          f"deflated {0 if w.outliers is None else w.outliers[1]}")
+    assert err / opt - 1 <= 1e-3
+    assert bool((lin.weight.data[mask] == 0).all())
