@@ -8,6 +8,13 @@
 #include "common.hpp"
 #include "../../include/slim_hip.h"
 #include "solver.hpp"
+#include "f32gemm.hpp"
+
+#define CHK(call)                   \
+    do {                            \
+        const int rc_ = (call);     \
+        if (rc_ != SLIM_OK) return rc_; \
+    } while (0)
 
 #define LP_BLOCKS 256
 
@@ -133,10 +140,34 @@ extern "C" int slim_lora_prune_optimize(float* L, float* R, const uint8_t* L_mas
     SLIM_REQUIRE(((uintptr_t)T % 16) == 0 && ((uintptr_t)workspace % 16) == 0, "slim_lora_prune_optimize: buffers must be 16-byte aligned");
     SLIM_REQUIRE(workspace_bytes >= slim_lora_prune_workspace_bytes(K, r, N), "slim_lora_prune_optimize: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    // the three fp32 products of an iteration run on the library's own fp32 MFMA GEMM (f32gemm.hip); rocBLAS sgemm only
+    // behind SLIM_PRUNE_LORA_LIBRARY_GEMM=1 (about twice as fast on these shapes, and a dlopen'd dependency)
+    static const bool library = getenv("SLIM_PRUNE_LORA_LIBRARY_GEMM") && atoi(getenv("SLIM_PRUNE_LORA_LIBRARY_GEMM")) != 0;
     rb_handle h = nullptr;
-    int rc = solver_handle(st, &h);
-    if (rc) return rc;
-    SLIM_REQUIRE(g_solver.sgemm, "slim_lora_prune_optimize: rocblas_sgemm not available");
+    if (library) {
+        int rc = solver_handle(st, &h);
+        if (rc) return rc;
+        SLIM_REQUIRE(g_solver.sgemm, "slim_lora_prune_optimize: rocblas_sgemm not available");
+    } else {
+        SLIM_REQUIRE(K % 4 == 0 && r % 4 == 0 && N % 4 == 0 && ((uintptr_t)L % 16) == 0 && ((uintptr_t)R % 16) == 0,
+                     "slim_lora_prune_optimize: K, r, N must be multiples of 4 and L, R 16-byte aligned");
+    }
+    // C [m, n] = A B with A, B row-major; a_t / b_t: the operand is stored transposed (A as [kd, m], B as [n, kd])
+    auto product = [&](const float* A, int lda, bool a_t, const float* B, int ldb, bool b_t, int m, int n, int kd, float* C) {
+        F32GemmArgs g;
+        g.A = A;
+        g.B = B;
+        g.C = C;
+        g.M = m;
+        g.N = n;
+        g.Kd = kd;
+        g.lda = lda;
+        g.ldb = ldb;
+        g.ldc = n;
+        g.a_kmajor = a_t ? 1 : 0;
+        g.b_kmajor = b_t ? 0 : 1;
+        return slim_f32gemm_launch(g, stream);
+    };
     LpWs w = lp_ws((char*)workspace, K, r, N);
     const int64_t nT = K * N, nL = K * r, nR = r * N;
     SLIM_HIP(hipMemsetAsync(w.mL, 0, (size_t)((char*)w.scal - (char*)w.mL), st));     // both moment pairs
@@ -149,9 +180,11 @@ extern "C" int slim_lora_prune_optimize(float* L, float* R, const uint8_t* L_mas
     SLIM_PROF("lora_prune_optimize", st, (double)num_iters * (8.0 * nT + 28.0 * (nL + nR)),
               (double)num_iters * 6.0 * K * r * N, num_iters > 0 ? num_iters : 1);
     for (int it = 0; it < num_iters; ++it) {
-        // row-major X [a, b] is the column-major b x a matrix X^T with leading dimension b
-        // D = L R:            D^T (N x K) = R^T (N x r) L^T (r x K)
-        if (g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, (int)N, (int)K, (int)r, &one, R, (int)N, L, (int)r, &zero, w.D, (int)N) != 0 ) {
+        // D = L R
+        if (!library) {
+            CHK(product(L, (int)r, false, R, (int)N, false, (int)K, (int)N, (int)r, w.D));
+        } else if (g_solver.sgemm(h, RB_OP_NONE, RB_OP_NONE, (int)N, (int)K, (int)r, &one, R, (int)N, L, (int)r, &zero, w.D, (int)N) != 0) {
+            // (row-major X [a, b] is the column-major b x a matrix X^T with leading dimension b: D^T = R^T L^T)
             slim_set_error("rocblas_sgemm failed");
             return SLIM_ERR_SOLVER;
         }
@@ -159,10 +192,12 @@ extern "C" int slim_lora_prune_optimize(float* L, float* R, const uint8_t* L_mas
         SLIM_LAUNCH_CHECK();
         lp_finish_kernel<<<1, LP_BLOCKS, 0, st>>>(w.part, w.scal, 0, losses ? losses + it : nullptr);
         SLIM_LAUNCH_CHECK();
-        // gL = D R^T:         gL^T (r x K) = (R^T)^T (r x N) D^T (N x K)
-        // gR = L^T D:         gR^T (N x r) = D^T (N x K) (L^T)^T (K x r)
-        if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, (int)r, (int)K, (int)N, &one, R, (int)N, w.D, (int)N, &zero, w.gL, (int)r) != 0 ||
-            g_solver.sgemm(h, RB_OP_NONE, RB_OP_TRANSPOSE, (int)N, (int)r, (int)K, &one, w.D, (int)N, L, (int)r, &zero, w.gR, (int)N) != 0) {
+        // gL = D R^T [K, r],  gR = L^T D [r, N]
+        if (!library) {
+            CHK(product(w.D, (int)N, false, R, (int)N, true, (int)K, (int)r, (int)N, w.gL));
+            CHK(product(L, (int)r, true, w.D, (int)N, false, (int)r, (int)N, (int)K, w.gR));
+        } else if (g_solver.sgemm(h, RB_OP_TRANSPOSE, RB_OP_NONE, (int)r, (int)K, (int)N, &one, R, (int)N, w.D, (int)N, &zero, w.gL, (int)r) != 0 ||
+                   g_solver.sgemm(h, RB_OP_NONE, RB_OP_TRANSPOSE, (int)N, (int)r, (int)K, &one, w.D, (int)N, L, (int)r, &zero, w.gR, (int)N) != 0) {
             slim_set_error("rocblas_sgemm failed");
             return SLIM_ERR_SOLVER;
         }
