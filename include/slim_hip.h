@@ -82,6 +82,12 @@ int slim_shift_zeros(const float* in, float* out, int64_t K, void* stream);
 int slim_sqrt_f32(const float* in, float* out, int64_t K, void* stream);
 /* flag[0] = 1 if any element is zero (the `any(scaler_row == 0)` guard of slim/lora.py:139) */
 int slim_any_zero_f32(const float* in, int64_t K, int32_t* flag, void* stream);
+/* The scalars the driver needs from one scaler_row vector before it compresses the layer, without host round trips per
+ * quantity: out_vals[0] = 1 if any entry is zero (the guard of slim/lora.py:139) else 0; out_vals[1] = the (lower) median
+ * of sqrt(scaler_row); out_vals[2 .. 2 + top) = the `top` largest values of sqrt(scaler_row) in decreasing order (equal
+ * values: lower index first; zero-filled past K) and out_idx[0 .. top) their indices.  top <= 128.  No counterpart in the
+ * reference: it serves the outlier deflation and the conditioning estimate of the low-rank fit (slim_lowrank_fit). */
+int slim_outlier_stats(const float* scaler_row, int64_t K, int top, float* out_vals, int32_t* out_idx, void* stream);
 
 /* ---- (2) N:M mask ------------------------------------------------------------------------ */
 

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "slim_shift_zeros": (i32, [vp, vp, i64, vp]),
     "slim_sqrt_f32": (i32, [vp, vp, i64, vp]),
     "slim_any_zero_f32": (i32, [vp, i64, vp, vp]),
+    "slim_outlier_stats": (i32, [vp, i64, i32, vp, vp, vp]),
     "slim_mask_nm": (i32, [vp, vp, i64, i64, i32, i32, vp, vp]),
     "slim_prune_nm_f32": (i32, [vp, i64, i64, i32, i32, vp, vp]),
     "slim_mask_unstructured": (i32, [vp, vp, i64, i64, i64, vp, vp]),

@@ -202,3 +202,118 @@ extern "C" int slim_any_zero_f32(const float* in, int64_t K, int32_t* flag, void
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
+
+
+// ---- per-linear scalars the driver needs before compressing a block --------------------------------------------------
+// From one scaler_row vector: whether any entry is zero (the guard of slim/lora.py:139), the median of sqrt(scaler_row)
+// (the lower median, as torch.median) and the `top` largest values of sqrt(scaler_row) in decreasing order with their
+// indices (equal values: lower index first).  The driver decides from these which input channels are outliers that the
+// low-rank fit represents exactly, and how wide a spectrum its orthonormalisations must cover.  One workgroup: radix
+// select on the float bit patterns (non-negative, so pattern order is value order), then a rank sort of the few winners.
+#define OS_THREADS 1024
+#define OS_MAX_TOP 128
+__global__ __launch_bounds__(OS_THREADS) void outlier_stats_kernel(const float* __restrict__ sr, int K, int top, int top_pad,
+                                                                  float* __restrict__ out_vals, int32_t* __restrict__ out_idx) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_target, s_count, s_fill;
+    __shared__ unsigned wave_cnt[OS_THREADS / 64];
+    __shared__ unsigned keys[OS_MAX_TOP];
+    __shared__ int idxs[OS_MAX_TOP];
+    __shared__ int s_zero;
+    const int t = threadIdx.x;
+    auto key_of = [&](int i) { return __float_as_uint(fabsf(sr[i])); };
+    if (t == 0) s_zero = 0, s_count = 0;
+    __syncthreads();
+    int z = 0;
+    for (int i = t; i < K; i += OS_THREADS) z |= sr[i] == 0.f;
+    if (z) s_zero = 1;
+    // key of ascending rank `target`
+    auto select = [&](unsigned target) {
+        unsigned prefix = 0, mask = 0;
+        for (int pass = 3; pass >= 0; --pass) {
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            for (int i = t; i < K; i += OS_THREADS) {
+                const unsigned k = key_of(i);
+                if ((k & mask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (t == 0) {
+                unsigned acc = 0;
+                int b = 0;
+                for (; b < 255; ++b) {
+                    if (acc + hist[b] > target) break;
+                    acc += hist[b];
+                }
+                s_target = target - acc;
+                s_prefix = prefix | ((unsigned)b << (8 * pass));
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            target = s_target;
+            mask |= 0xffu << (8 * pass);
+            __syncthreads();
+        }
+        return prefix;
+    };
+    const unsigned med = select((unsigned)(K - 1) / 2);
+    const unsigned thr = select((unsigned)(K - top));          // the top-th largest key
+    // strictly larger keys: at most top - 1 of them, in any order (they are sorted below)
+    for (int i = t; i < K; i += OS_THREADS) {
+        const unsigned k = key_of(i);
+        if (k > thr) {
+            const unsigned p = atomicAdd(&s_count, 1u);
+            keys[p] = k;
+            idxs[p] = i;
+        }
+    }
+    __syncthreads();
+    if (t == 0) s_fill = s_count;
+    __syncthreads();
+    // keys equal to the threshold fill the rest, lowest indices first
+    for (int base = 0; base < K; base += OS_THREADS) {
+        if (s_fill >= (unsigned)top) break;
+        const int i = base + t;
+        const bool tie = i < K && key_of(i) == thr;
+        const unsigned long long b = __ballot(tie);
+        if ((t & 63) == 0) wave_cnt[t >> 6] = (unsigned)__popcll(b);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (int w = 0; w < OS_THREADS / 64; ++w) {
+            if (w < (t >> 6)) before += wave_cnt[w];
+            total += wave_cnt[w];
+        }
+        const unsigned pos = s_fill + before + (unsigned)__popcll(b & ((1ull << (t & 63)) - 1ull));
+        if (tie && pos < (unsigned)top) {
+            keys[pos] = thr;
+            idxs[pos] = i;
+        }
+        __syncthreads();
+        if (t == 0) s_fill += total;
+        __syncthreads();
+    }
+    if (t == 0) {
+        out_vals[0] = s_zero ? 1.f : 0.f;
+        out_vals[1] = sqrtf(__uint_as_float(med));
+    }
+    if (t < top) {
+        const unsigned k = keys[t];
+        const int idx = idxs[t];
+        int rank = 0;
+        for (int j = 0; j < top; ++j) rank += (keys[j] > k) || (keys[j] == k && idxs[j] < idx);
+        out_vals[2 + rank] = sqrtf(__uint_as_float(k));
+        out_idx[rank] = idx;
+    } else if (t < top_pad) {
+        out_vals[2 + t] = 0.f;
+        out_idx[t] = 0;
+    }
+}
+
+extern "C" int slim_outlier_stats(const float* scaler_row, int64_t K, int top, float* out_vals, int32_t* out_idx, void* stream) {
+    SLIM_REQUIRE(scaler_row && out_vals && out_idx, "slim_outlier_stats: null pointer");
+    SLIM_REQUIRE(K > 0 && K < (1 << 30) && top > 0 && top <= OS_MAX_TOP, "slim_outlier_stats: bad sizes");
+    const int have = top < K ? top : (int)K;
+    outlier_stats_kernel<<<1, OS_THREADS, 0, (hipStream_t)stream>>>(scaler_row, (int)K, have, top, out_vals, out_idx);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}

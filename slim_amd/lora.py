@@ -213,10 +213,10 @@ def outlier_columns(scaler_row, max_cols=MAX_OUTLIER_COLS, rank=None):
     """((indices of the outlier columns padded to a multiple of 8, number of real outliers) or None, spread of
     the remaining scales).  One host synchronisation; the driver precomputes the same quantities for a
     whole block at once (prune.block_stats).  rank: the adapter rank of the layer (None: not limiting)."""
-    s = torch.sqrt(scaler_row)
-    top = torch.topk(s, min(max_cols + 1, s.numel()))
-    host = torch.cat([top.values, s.median().reshape(1)]).cpu()
-    return _outliers_from_host(host[:-1].tolist(), float(host[-1]), top.indices, rank)
+    vals, idx = ops.outlier_stats(scaler_row, max_cols + 1)
+    host = vals.cpu().tolist()
+    k = min(max_cols + 1, scaler_row.numel())
+    return _outliers_from_host(host[2:2 + k], host[1], idx[:k], rank)
 
 
 def _outliers_from_host(top_vals, median, top_idx, rank=None):

@@ -108,6 +108,17 @@ def any_zero(v):
     return bool(any_zero_flag(v).item())
 
 
+def outlier_stats(scaler_row, top, out_vals=None, out_idx=None):
+    """(vals fp32 [2 + top], idx int32 [top]) of slim_outlier_stats: any-zero flag, median of sqrt(scaler_row), the `top`
+    largest sqrt values in decreasing order and their indices.  out_vals / out_idx: rows of preallocated tensors."""
+    v = _chk(scaler_row, torch.float32, "scaler_row")
+    if out_vals is None:
+        out_vals = torch.empty(2 + top, dtype=torch.float32, device=v.device)
+        out_idx = torch.empty(top, dtype=torch.int32, device=v.device)
+    _lib.call("slim_outlier_stats", _p(v), v.numel(), int(top), _p(out_vals), _p(out_idx), _stream())
+    return out_vals, out_idx
+
+
 # ---- N:M mask --------------------------------------------------------------------------------
 def mask_nm(W, s, n, m):
     """Fused saliency |W| * s and N:M selection; returns a bool [N, K] tensor (True = pruned)."""

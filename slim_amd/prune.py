@@ -68,18 +68,17 @@ def block_stats(wrapped_list, rank_of=None):
         rank_of = lambda w: max(1, min(w.rows, w.columns) // 10)
     if not wrapped_list:            # a rank that owns no linear of this block
         return
-    rows, idxs = [], []
-    for w in wrapped_list:
-        s = torch.sqrt(w.scaler_row)
-        k = min(MAX_OUTLIER_COLS + 1, s.numel())
-        top = torch.topk(s, k)
-        vals = torch.nn.functional.pad(top.values, (0, MAX_OUTLIER_COLS + 1 - k))
-        rows.append(torch.cat([ops.any_zero_flag(w.scaler_row).float().reshape(1), s.median().reshape(1), vals]))
-        idxs.append((top.indices, k))
-    host = torch.stack(rows).cpu()
-    for w, row, (idx, k) in zip(wrapped_list, host.tolist(), idxs):
+    top = MAX_OUTLIER_COLS + 1
+    dev = wrapped_list[0].scaler_row.device
+    vals = torch.empty(len(wrapped_list), 2 + top, dtype=torch.float32, device=dev)
+    idxs = torch.empty(len(wrapped_list), top, dtype=torch.int32, device=dev)
+    for j, w in enumerate(wrapped_list):
+        ops.outlier_stats(w.scaler_row, top, vals[j], idxs[j])
+    host = vals.cpu()                                               # the block's one synchronisation
+    for j, (w, row) in enumerate(zip(wrapped_list, host.tolist())):
+        k = min(top, w.scaler_row.numel())
         w.has_zero = bool(row[0])
-        w.outliers, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idx, rank_of(w))
+        w.outliers, w.scale_spread = _outliers_from_host(row[2:2 + k], row[1], idxs[j, :k], rank_of(w))
 
 
 # SLIM_STREAM_TRACE=1: run_on_streams records, per job, when its host thread started / finished enqueueing and when its

@@ -483,3 +483,38 @@ def test_lowrank_fit_library_eigh_agrees(ops):
     print("reconstruction error: in-library", outs[False][0], "syevd", outs[True][0])
     assert abs(outs[False][0] / outs[True][0] - 1) <= 2e-4
     torch.testing.assert_close(outs[False][1][: r // 2], outs[True][1][: r // 2], rtol=1e-4, atol=0)
+
+
+def test_outlier_stats_match_torch(ops):
+    """slim_outlier_stats against torch.topk / torch.median / (== 0).any() on sqrt(scaler_row): ties, zeros, vectors
+    shorter than the list, the widths of the benchmark layers."""
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for K in (8, 40, 65, 66, 1000, 4096, 11008, 28672):
+        sr = (torch.exp(torch.randn(K, generator=g)) ** 2).float()
+        cases.append(sr.clone())
+        sr2 = sr.clone()
+        sr2[torch.randperm(K, generator=g)[:3]] *= 1e4                      # outliers
+        sr2[torch.randperm(K, generator=g)[:2]] = 0.0                       # dead channels
+        cases.append(sr2)
+        sr3 = torch.round(sr * 4) / 4                                       # many exact ties, also at the cut
+        cases.append(sr3)
+    cases.append(torch.full((300,), 2.5))                                   # all equal
+    for sr in cases:
+        K = sr.numel()
+        top = 65
+        vals, idx = ops.outlier_stats(sr.to(DEV), top)
+        vals, idx = vals.cpu(), idx.cpu().long()
+        s = torch.sqrt(sr.to(DEV)).cpu()      # (the CPU's vectorised sqrt is an ulp off on a host-dependent subset of inputs)
+        k = min(top, K)
+        ref = torch.topk(s, k)
+        assert bool(vals[0]) == bool((sr == 0).any())
+        assert float(vals[1]) == float(s.median()), (K, float(vals[1]), float(s.median()))
+        assert torch.equal(vals[2:2 + k], ref.values), K
+        assert torch.equal(s[idx[:k]], ref.values)                           # the indices point at those values
+        assert len(set(idx[:k].tolist())) == k                               # ... and are distinct
+        # equal values: lower index first
+        for a in range(k - 1):
+            if vals[2 + a] == vals[3 + a]:
+                assert idx[a] < idx[a + 1]
+        assert bool((vals[2 + k:] == 0).all())
