@@ -190,10 +190,8 @@ int slim_lora_prune_optimize(float* L, float* R, const uint8_t* L_mask, const fl
                              int num_iters, float lr, float lr_end_factor, float* losses, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
-/* Tuning aid: force the workgroup tile of every following GEMM launch in this process (register-staged 0: 128x128,
- * 1: 128x64, 2: 64x128, 3: 64x64, 11: 128x128 with 32-deep K-steps; LDS-DMA pipelines 4: 128x128 x 3 stages,
- * 5: 128x64 x 3, 6: 64x128 x 3, 7: 64x64 x 4, 8: 128x128 K32 x 6, 9: 64x64 K32 x 6, 10: 128x128 x 4; anything else:
- * chosen per shape family, the default).  Results do not depend on the tile. */
+/* Tuning aid: force the workgroup tile of every following GEMM launch in this process (0: 128x128, 1: 128x64,
+ * 2: 64x128, 3: 64x64; anything else: the library's choice, 128x128, the default).  Results do not depend on the tile. */
 void slim_gemm_set_tile(int tile);
 /* The same for one shape family (0: small output with a long reduction, 1: l x l x l, 2: tall x (l x l),
  * 3: products with the error matrix, 4: large square, 5: residual); -1 restores the library's choice. */

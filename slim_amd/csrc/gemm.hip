@@ -22,12 +22,10 @@
 // small (a few hundred tiles at most) and each workgroup's K-loop is bound by load latency: more, smaller workgroups
 // keep more loads in flight per CU and fill the 256 CUs.
 // Variants 0-3 stage tiles through registers (one K-step ahead, padded LDS rows); 4+ use LDS-DMA, several stages deep.
-enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, DMA_128x128_S3, DMA_128x64_S3, DMA_64x128_S3, DMA_64x64_S4,
-       DMA_128x128_K32_S6, DMA_64x64_K32_S6, DMA_128x128_S4, TILE_128x128_K32, TILE_COUNT };
-static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 128};
-static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 128, 128};
-static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32};
-static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 3, 3, 3, 4, 6, 6, 4, 0};     // 0: register-staged
+enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, TILE_COUNT };
+static const int kTileM[TILE_COUNT] = {128, 128, 64, 64};
+static const int kTileN[TILE_COUNT] = {128, 64, 128, 64};
+static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64};
 
 // BKT elements of the reduction per tile row: BKT / 8 threads cover a row, 2048 / BKT rows per pass of the 256 threads
 template <int ROWS, int BKT>
@@ -431,165 +429,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     gemm_stamp(g, 3);
 }
 
-// ---- the same product with the operand tiles copied global -> LDS by LDS-DMA, NST stages deep -------------------------
-// A workgroup's K-loop is bound by load latency (operands come from HBM / Infinity Cache, a microsecond away, while a
-// K-step of MFMAs takes a fifth of that), so what counts is how many K-steps of operands are in flight.  LDS-DMA loads
-// (global_load_lds) need no staging registers: NST LDS buffers hold NST - 1 tiles in flight while one is consumed.
-// The LDS image of a tile is written linearly by the DMA (64 lanes x 16 bytes per instruction), so the bank-conflict
-// swizzle is applied to the per-lane SOURCE address and again when the fragments are read: row r keeps its 16-byte
-// chunk c at slot c ^ swz(r).  Chunks beyond Kd are fetched from a 16-byte block of zeros.
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef const __attribute__((address_space(1))) void global_cvoid;
-__device__ __attribute__((aligned(16))) bf16_t g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
-template <int BKT>
-__device__ __forceinline__ int swz(int r) {
-    constexpr int SP = BKT / 8;             // 16-byte slots per row: 8 (BK 64) or 4 (BK 32)
-    return (r / (16 / SP)) % SP;            // rows r .. r + 15 at one chunk then cover all 64 banks once
-}
-
-template <int ROWS, int BKT>
-__device__ __forceinline__ void glds_tile(const bf16_t* __restrict__ P, int64_t ld, int rows, int Kd, int row0, int k0,
-                                          bf16_t* lds_tile) {
-    constexpr int SP = BKT / 8, RPI = 64 / SP, NI = ROWS / RPI / 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int inst = wave * NI + i;                  // 1 KiB piece of the tile image
-        const int r = inst * RPI + lane / SP;
-        const int chunk = (lane % SP) ^ swz<BKT>(r);
-        int grow = row0 + r;
-        grow = grow < rows ? grow : rows - 1;
-        const int k = k0 + chunk * 8;
-        const bf16_t* src = k < Kd ? P + (int64_t)grow * ld + k : g_zero_chunk;
-        __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_u32*)(uintptr_t)(lds_tile + inst * 512), 16, 0, 0);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm_lgkm0() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
-
-template <int FAMILY, int FM, int FN, int BKT, int NST>
-__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
-    constexpr int BM = 32 * FM, BN = 32 * FN;
-    constexpr int STAGE = (BM + BN) * BKT;                               // elements per stage
-    constexpr int LOADS = (BM + BN) / (64 / (BKT / 8)) / 4;              // LDS-DMA instructions per wave per stage
-    static_assert((NST - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    int row0, col0;
-    gemm_tile_origin<BM, BN>(g, row0, col0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    gemm_stamp(g, 0);
-    const int nk_total = (g.Kd + BKT - 1) / BKT;
-    const int per_split = g.ksteps_per_split * (BK / BKT);               // the plan counts 64-deep steps
-    const int kt0 = g.splits > 1 ? (int)blockIdx.y * per_split : 0;
-    const int nk = g.splits > 1 ? min(per_split, nk_total - kt0) : nk_total;
-    // every stage issues the same number of loads per wave, also past the end of the reduction (those read the zero
-    // block), so that the counted waits below always mean "all but the newest NST - 2 stages have landed"
-    auto issue = [&](int kt) {
-        bf16_t* buf = smem + (kt % NST) * STAGE;
-        const int k0 = kt < nk ? (kt0 + kt) * BKT : g.Kd;
-        glds_tile<BM, BKT>(g.A, g.lda, g.M, g.Kd, row0, k0, buf);
-        glds_tile<BN, BKT>(g.B, g.ldb, g.N, g.Kd, col0, k0, buf + BM * BKT);
-    };
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s) issue(s);
-    wait_vm_lgkm0<(NST - 2) * LOADS>();
-    __builtin_amdgcn_s_barrier();
-    gemm_stamp(g, 1);
-
-    // fragment rows of this lane and their swizzles do not change over the loop
-    int a_off[FM], b_off[FN], a_sw[FM], b_sw[FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int r = wr * 16 * FM + i * 16 + fr;
-        a_off[i] = r * BKT;
-        a_sw[i] = swz<BKT>(r);
-    }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int r = wc * 16 * FN + j * 16 + fr;
-        b_off[j] = BM * BKT + r * BKT;
-        b_sw[j] = swz<BKT>(r);
-    }
-
-    if constexpr (BKT == 64) {
-        // All sixteen fragment reads of a K-step are issued at once, ahead of the DMA issue block and of the MFMAs: with
-        // one wave per SIMD nothing else hides the LDS latency, and taken in four read-wait-MFMA rounds (the order the
-        // compiler picks to save registers) it costs three times the MFMA time of the K-step.
-        bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
-        auto read = [&](const bf16_t* buf, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
-            const int c = ks * 4 + fq;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(buf + a_off[i] + ((c ^ a_sw[i]) << 3));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(buf + b_off[j] + ((c ^ b_sw[j]) << 3));
-        };
-        auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&bfr)[FN]) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        };
-        for (int kt = 0; kt < nk; ++kt) {
-            const bf16_t* buf = smem + (kt % NST) * STAGE;
-            read(buf, 0, a0, b0);
-            read(buf, 1, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            // the buffer refilled here held stage kt-1, whose reads were retired before the previous barrier; the address
-            // arithmetic of the eight DMA issues runs while the sixteen LDS reads above are in flight
-            issue(kt + NST - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);                                  // needs only the first half of the reads
-            mma(a1, b1);
-            wait_vm_lgkm0<(NST - 2) * LOADS>();           // own share of stage kt+1 has landed
-            __builtin_amdgcn_s_barrier();
-        }
-    } else {
-    for (int kt = 0; kt < nk; ++kt) {
-        // the buffer refilled here was read in the previous iteration; every wave has passed that iteration's barrier
-        // with its LDS reads retired
-        issue(kt + NST - 1);
-        const bf16_t* buf = smem + (kt % NST) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < BKT / 32; ++ks) {
-            bf16x8 af[FM], bfr[FN];
-            const int c = ks * 4 + fq;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(buf + a_off[i] + ((c ^ a_sw[i]) << 3));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(buf + b_off[j] + ((c ^ b_sw[j]) << 3));
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        // own share of stage kt + 1 has landed and own reads of stage kt are retired; after the barrier that holds
-        // for every wave
-        wait_vm_lgkm0<(NST - 2) * LOADS>();
-        __builtin_amdgcn_s_barrier();
-    }
-    }
-    // the dummy stages issued past the end still target LDS: let them land before the workgroup retires
-    wait_vm_lgkm0<0>();
-    gemm_stamp(g, 2);
-    gemm_epilogue<FM, FN>(g, acc, (float*)smem, row0, col0, wr, wc, fr, fq);
-    gemm_stamp(g, 3);
-}
-
 // C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order.  One 64 x 64 tile per
 // workgroup, read as 16-byte pieces of every slice.  Symmetric products fill only the 128 x 128 tiles on and above the
 // diagonal: the workgroups of the tiles below it leave at once, those above it write their tile and, through LDS, its
@@ -742,14 +581,6 @@ static gemm_kernel_t gemm_kernel_of(int tile) {
         case TILE_128x64: return gemm_nt_kernel<FAMILY, 4, 2>;
         case TILE_64x128: return gemm_nt_kernel<FAMILY, 2, 4>;
         case TILE_64x64: return gemm_nt_kernel<FAMILY, 2, 2>;
-        case DMA_128x128_S3: return gemm_nt_glds_kernel<FAMILY, 4, 4, 64, 3>;
-        case DMA_128x64_S3: return gemm_nt_glds_kernel<FAMILY, 4, 2, 64, 3>;
-        case DMA_64x128_S3: return gemm_nt_glds_kernel<FAMILY, 2, 4, 64, 3>;
-        case DMA_64x64_S4: return gemm_nt_glds_kernel<FAMILY, 2, 2, 64, 4>;
-        case DMA_128x128_K32_S6: return gemm_nt_glds_kernel<FAMILY, 4, 4, 32, 6>;
-        case DMA_64x64_K32_S6: return gemm_nt_glds_kernel<FAMILY, 2, 2, 32, 6>;
-        case DMA_128x128_S4: return gemm_nt_glds_kernel<FAMILY, 4, 4, 64, 4>;
-        case TILE_128x128_K32: return gemm_nt_kernel<FAMILY, 4, 4, 32>;
         default: return gemm_nt_kernel<FAMILY, 4, 4>;
     }
 }
@@ -813,8 +644,7 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
-    const int loop_bytes = kTileStages[tile] ? kTileStages[tile] * (BM + BN) * kTileBK[tile] * (int)sizeof(bf16_t)
-                                             : 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
+    const int loop_bytes = 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
     const int epilogue_bytes = BM * (BN + 1) * (int)sizeof(float);       // the output tile staged as fp32
     const int lds_bytes = loop_bytes > epilogue_bytes ? loop_bytes : epilogue_bytes;
     static const char* const names[FAM_COUNT] = {"gemm_nt_gram", "gemm_nt_small", "gemm_nt_apply", "gemm_nt_sketch",

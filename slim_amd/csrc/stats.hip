@@ -238,15 +238,26 @@ __global__ __launch_bounds__(OS_THREADS) void outlier_stats_kernel(const float* 
                 if ((k & mask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1u);
             }
             __syncthreads();
-            if (t == 0) {
-                unsigned acc = 0;
-                int b = 0;
-                for (; b < 255; ++b) {
-                    if (acc + hist[b] > target) break;
-                    acc += hist[b];
+            if (t < 64) {
+                // the bin that holds rank `target`: lane t sums bins 4 t .. 4 t + 3, a wave prefix sum places it
+                const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+                const unsigned mine = h0 + h1 + h2 + h3;
+                unsigned incl = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned up = __shfl_up(incl, d);
+                    if (t >= d) incl += up;
                 }
-                s_target = target - acc;
-                s_prefix = prefix | ((unsigned)b << (8 * pass));
+                const unsigned before = incl - mine;
+                if (target >= before && target < incl) {
+                    unsigned acc = before;
+                    int b = 4 * t;
+                    if (acc + h0 <= target) { acc += h0, ++b;
+                        if (acc + h1 <= target) { acc += h1, ++b;
+                            if (acc + h2 <= target) { acc += h2, ++b; } } }
+                    s_target = target - acc;
+                    s_prefix = prefix | ((unsigned)b << (8 * pass));
+                }
             }
             __syncthreads();
             prefix = s_prefix;
