@@ -86,7 +86,10 @@ def block_stats(wrapped_list, rank_of=None):
 STREAM_TRACE = os.environ.get("SLIM_STREAM_TRACE", "0") == "1"
 # SLIM_STREAM_THREADS=0: the calling thread feeds the side streams one after the other (slower: one thread enqueues
 # everything; for profilers that do not tolerate dispatches from several threads)
-STREAM_THREADS = os.environ.get("SLIM_STREAM_THREADS", "1") != "0"
+# Under rocprofv3 (its launcher exports ROCPROF_* variables to the profiled process) the streams are always fed by the
+# calling thread: dispatches from several host threads while the profiler intercepts them took a GPU node down once.
+PROFILER_ATTACHED = any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
+STREAM_THREADS = os.environ.get("SLIM_STREAM_THREADS", "1") != "0" and not PROFILER_ATTACHED
 LAST_STREAM_TRACE = []
 
 
