@@ -226,16 +226,24 @@ def main():
         for i in mine:
             packed[i] = ops.pack24(lins[i].weight.data, lins[i].scaling_factor, check=False)
         if world > 1:
-            # exchange step: every rank receives the compressed shards of the linears it does not own
+            # exchange step: every rank receives the compressed linears it does not own -- the weight in the packed form made
+            # above (0.375 byte per element), expanded by the receiver -- and the adapters
             for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK):
                 lin = lins[i]
+                r = 512 if min(n, k) >= 4096 else 256
                 if owner[i] != rank:
-                    r = 512 if min(n, k) >= 4096 else 256
-                    lin.weight.data = torch.empty(n, k, dtype=torch.bfloat16, device=dev)
+                    vb, mb = ops.packed24_bytes(n, k)
+                    vals = torch.empty(vb, dtype=torch.uint8, device=dev)
+                    meta = torch.empty(mb, dtype=torch.uint8, device=dev)
+                    lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=dev)
                     lin.lora_left = torch.nn.Parameter(torch.empty(k, r, dtype=torch.bfloat16, device=dev))
                     lin.lora_right = torch.nn.Parameter(torch.empty(r, n, dtype=torch.bfloat16, device=dev))
-                for t in (lin.weight.data, lin.lora_left.data, lin.lora_right.data):
+                else:
+                    vals, meta, _ = packed[i]
+                for t in (vals, meta, lin.scaling_factor, lin.lora_left.data, lin.lora_right.data):
                     parallel.broadcast(t, owner[i])          # RCCL broadcast (host-staged only under a gloo rehearsal)
+                if owner[i] != rank:
+                    lin.weight.data = ops.unpack24(vals, meta, lin.scaling_factor.reshape(1), n, k)
 
     def step_rows(n_streams=None):
         # statistics: every rank sums its share of the samples, the per-sample sums are gathered into sample order and
@@ -389,7 +397,7 @@ def main():
                        "partition": ("one GPU" if world == 1 else
                                      f"row blocks of every linear over {world} ranks, samples sharded; histogram / Rayleigh-Ritz "
                                      "all-reduce, Gram reduce, all-gather of compressed blocks" if mode == "rows" else
-                                     f"whole linears over {world} ranks by cost + broadcast of the compressed linears"),
+                                     f"whole linears over {world} ranks by cost + broadcast of the compressed linears (weights in packed form)"),
                        "partition_trial_ms": {m: round(v, 2) for m, v in trial.items()} or None,
                        "compression_only_extrapolated_s": ms_per_step * 32 / 1e3,
                        "ms_per_step_with_event_timers": dt_instrumented / args.steps * 1e3},

@@ -95,16 +95,27 @@ def all_gather(t, group=None):
     return out
 
 
+def packable(N, K, prune_n, prune_m, bits):
+    """Whether a compressed weight of this shape and recipe has the packed 2:4 int4 form (0.375 byte per element)."""
+    return prune_n == 2 and prune_m == 4 and bits == 4 and N % 128 == 0 and K % 64 == 0
+
+
 def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True, scale_dtype=torch.float32,
-                    has_left_mask=False):
+                    has_left_mask=False, packed=False):
     """Broadcast one compressed linear from its owner.  shapes = (N, K, r).  Non-owners allocate receive
     buffers; afterwards every rank holds weight.data [N, K], lora_left [K, r], lora_right [r, N],
     scaling_factor (1, 1) in scale_dtype (fp32 under SLiM-Quant, bf16 under abs-max: what the owner's quantiser
-    leaves) and, for pruned adapters, lora_left_mask [K, r] (bool)."""
+    leaves) and, for pruned adapters, lora_left_mask [K, r] (bool).
+    packed=True (a 2:4 sparse 4-bit weight, see packable): the weight travels in its packed form -- codes and positions,
+    0.375 byte per element instead of 2 -- and the receivers expand it; pack and unpack are exact inverses on such
+    weights up to the sign of zeros (a level that rounds to -0 arrives as +0), so the receivers' tensor equals the
+    owner's under ==."""
+    from . import ops
     N, K, r = shapes
     dt = lin.weight.dtype
     if owner != rank:
-        lin.weight.data = torch.empty(N, K, dtype=dt, device=device)
+        if not packed:
+            lin.weight.data = torch.empty(N, K, dtype=dt, device=device)
         lin.lora_left = torch.nn.Parameter(torch.empty(K, r, dtype=dt, device=device), requires_grad=False)
         lin.lora_right = torch.nn.Parameter(torch.empty(r, N, dtype=dt, device=device), requires_grad=False)
         lin.scaling_factor = torch.empty(1, 1, dtype=scale_dtype, device=device) if has_scale else None
@@ -112,11 +123,27 @@ def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True
             lin.lora_left_mask = torch.empty(K, r, dtype=torch.bool, device=device)
     elif has_scale and lin.scaling_factor.dtype != scale_dtype:
         raise TypeError(f"scaling factor of the owner is {lin.scaling_factor.dtype}, the exchange expects {scale_dtype}")
-    tensors = [lin.weight.data, lin.lora_left.data, lin.lora_right.data]
+    tensors = [lin.lora_left.data, lin.lora_right.data]
     if has_scale:
         tensors.append(lin.scaling_factor)
+    if packed:
+        if not has_scale:
+            raise ValueError("the packed exchange needs the weight's scaling factor")
+        if owner == rank:
+            # (the status word -- not 2:4, or not 4-bit levels of this scale -- is left on the module for the caller to
+            # read once per block)
+            vals, meta, lin.pack_status = ops.pack24(lin.weight.data, lin.scaling_factor.float().reshape(1), check=False)
+        else:
+            vb, mb = ops.packed24_bytes(N, K)
+            vals = torch.empty(vb, dtype=torch.uint8, device=device)
+            meta = torch.empty(mb, dtype=torch.uint8, device=device)
+        tensors += [vals, meta]
+    else:
+        tensors.append(lin.weight.data)
     for t in tensors:
         broadcast(t, owner, group)
+    if packed and owner != rank:
+        lin.weight.data = ops.unpack24(vals, meta, lin.scaling_factor.float().reshape(1), N, K)
     if has_left_mask:
         m8 = lin.lora_left_mask.to(torch.uint8)         # bool has no reduction/broadcast support in every backend
         broadcast(m8, owner, group)

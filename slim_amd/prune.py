@@ -479,7 +479,7 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
 
 
 def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora_tile_size, has_scale, separate_lora=True,
-                    scale_dtype=torch.float32, prune_lora=False):
+                    scale_dtype=torch.float32, prune_lora=False, recipe=(0, 0, 0)):
     """Every rank receives the compressed form of the linears it does not own (weight, adapters, scale, mask of pruned
     adapters) and gives them the attributes and the hook the owner's copy has."""
     from .lora import lora_rank as rank_of
@@ -489,8 +489,9 @@ def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora
         if lora_rank > 0. and separate_lora:
             r = min(rank_of((N, K), lora_rank, lora_tile_size if tiled_rank else None), min(N, K))
             mine = owner[j] == rank
+            # a 2:4 sparse 4-bit weight travels packed (0.375 instead of 2 bytes per element), recipe = (n, m, bits)
             parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale, scale_dtype=scale_dtype,
-                                     has_left_mask=prune_lora)
+                                     has_left_mask=prune_lora, packed=has_scale and parallel.packable(N, K, *recipe))
             if not mine:
                 lin.lora_rank = torch.tensor(r)
                 lin.register_forward_hook(add_lora_hook)
@@ -500,6 +501,12 @@ def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora
                 if owner[j] != rank:
                     lin.scaling_factor = torch.empty(1, 1, dtype=scale_dtype, device=dev)
                 parallel.broadcast(lin.scaling_factor, owner[j])
+    # the owners' packing status words, read with one synchronisation
+    pending = [(n, subset[n].__dict__.pop("pack_status")) for n in names if "pack_status" in subset[n].__dict__]
+    if pending:
+        for (n, _), st in zip(pending, torch.cat([p for _, p in pending]).cpu().tolist()):
+            if st:
+                raise ValueError(f"{n}: the compressed weight does not have the packed 2:4 int4 form (status {st})")
 
 
 def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quantize_weight=False, bitwidth=4,
@@ -587,7 +594,8 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
             if world > 1:
                 _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
                                 quantizer is not None and not tiled_weight_quantization, separate_lora,
-                                torch.float32 if slim_quant else torch.bfloat16, prune_lora)
+                                torch.float32 if slim_quant else torch.bfloat16, prune_lora,
+                                (prune_n, prune_m, bitwidth if (quantizer is not None and quantize_first) else 0))
 
         progress_bar.set_description(f"Layer {i} - Evaluating Output")
         _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
