@@ -41,6 +41,9 @@ SHARED_EIGH = os.environ.get("SLIM_SHARED_EIGH", "1") == "1"
 # as one lockstep chain (SLIM_GROUP_FITS=0: one chain per linear)
 GROUP_FITS = os.environ.get("SLIM_GROUP_FITS", "1") == "1"
 GROUP_MAX = int(os.environ.get("SLIM_GROUP_MAX", "0"))
+# with lockstep groups: every group runs its own eigen-solver chain right after its front instead of all groups meeting
+# in one batched chain (SLIM_PIPELINE_GROUPS=0 restores that; measured 23.6 against 24.3 ms per block)
+PIPELINE_GROUPS = os.environ.get("SLIM_PIPELINE_GROUPS", "1") == "1"
 # which of the side streams carry the chains when there are at most that many: HIP spreads a process's streams over four
 # in-order hardware queues, and these four of the seven side streams sit on four different ones
 GROUP_STREAM_IDS = [int(x) for x in os.environ.get("SLIM_GROUP_STREAMS", "0,1,2,6").split(",") if x != ""]
@@ -454,9 +457,29 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                     _lora.add_lora_fit_back_group([ctxs[i] for i in members], d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
                 return [x for i in members for x in ctxs[i].tensors()]
 
-            # (splitting the linears into two groups so that one group's chain overlaps the other's GEMM-heavy halves was
-            # measured slower, 56.7 vs 47 ms: the extra barriers cost more than the idle chip during the shared chain)
             ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
+            if PIPELINE_GROUPS and len(fit_groups) <= 4:
+                # every group runs its whole chain -- front, its own batched eigen-solver chain, factors, finishes -- on its
+                # stream without waiting for the others: the latency-bound eigen-solver launches of a group that is done
+                # early overlap the GEMMs of the groups still in their fronts
+                def whole_group(g):
+                    members = fit_groups[g][1]
+                    l, b0 = where[g]
+                    out = front(g)
+                    sl = slice(b0, b0 + len(members))
+                    Mg = Mb[l][sl]
+                    d, e, Q = ops.tridiagonalize_batched(Mg)
+                    r_fit = ctxs[members[0]].pending["ctx"]["r"]
+                    tail = ops.eigh_tail(d, e, Q, Mg, r_fit)
+                    if gbuf[g] is None:
+                        _lora.add_lora_fit_back(ctxs[members[0]], d[0], e[0], Q[0], Mg[0], tail[0:1])
+                    else:
+                        _lora.add_lora_fit_back_group([ctxs[i] for i in members], d, e, Q, Mg, tail)
+                    for i in members:
+                        out += finish(i)
+                    return out + [d, e, Q, tail]
+                run_on_streams([lambda g=g: whole_group(g) for g in range(len(fit_groups))], dev, n_streams, ids)
+                return
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             # the eigenproblems of the block, size by size: one tridiagonalisation chain and three launches for the
             # tridiagonal stage, each carrying every problem of that size

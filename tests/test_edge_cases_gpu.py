@@ -118,11 +118,11 @@ def test_stream_feeding_modes_agree(ops):
         P.STREAM_THREADS, P.STREAM_TRACE = threads, trace
         try:
             items = []
-            for i in range(3):
-                lin = torch.nn.Linear(256, 128, bias=False, device=DEV, dtype=torch.bfloat16)
-                lin.weight.data = synth_weight(128, 256, 40 + i).to(DEV)
+            for i, (n, k) in enumerate([(128, 256), (256, 256), (256, 128)]):     # three shapes: three chains, one per stream
+                lin = torch.nn.Linear(k, n, bias=False, device=DEV, dtype=torch.bfloat16)
+                lin.weight.data = synth_weight(n, k, 40 + i).to(DEV)
                 wr = WrappedGPT(lin)
-                wr.add_batch(synth_weight(64, 256, 50 + i, sigma=1.0).to(DEV).reshape(1, 64, 256), None)
+                wr.add_batch(synth_weight(64, k, 50 + i, sigma=1.0).to(DEV).reshape(1, 64, k), None)
                 wr.scaler_row = ops.shift_zeros(wr.scaler_row)
                 items.append((f"l{i}", lin, wr))
             P.compress_linears(items, torch.device(DEV), 2, 4, quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
