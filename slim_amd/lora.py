@@ -18,6 +18,16 @@ from .utils import get_layers_list, find_layers
 FIT_OVERSAMPLE_DIV = 8
 FIT_MIN_OVERSAMPLE = 64
 FIT_ITERS = 10
+# larger subspaces (rank 1024 on the 8192 x 28672 layers of a 70B-shaped model: l = 1152) meet flatter spectra: measured
+# excess there 9.8e-4 after 10 iterations, 6.5e-4 after 12, 4.5e-4 after 14 (0.7 ms of a 24 ms fit each)
+FIT_ITERS_LARGE_EXTRA = 4
+FIT_LARGE_L = 768
+
+
+def fit_iters(l):
+    """Subspace iterations for a fit with subspace dimension l."""
+    return FIT_ITERS + (FIT_ITERS_LARGE_EXTRA if l > FIT_LARGE_L else 0)
+
 FIT_SEED = 0
 # orthonormalise the iterates by Cholesky-QR through rocSOLVER instead of Newton-Schulz on MFMA
 FIT_CHOLESKY_QR = os.environ.get("SLIM_FIT_CHOLESKY_QR", "0") == "1"
@@ -127,7 +137,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
     if t:
         E, UO, Ct, info_o = deflate_outliers(E, Et, outliers)
         Et = ops.transpose(E)
-    fit = ops.lowrank_fit(E, Et, rf, over, FIT_ITERS, seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
+    fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
                           ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
                           sketch_split=FIT_SKETCH_SPLIT)
     return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
@@ -164,7 +174,7 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
     if t:
         E, p["UO"], p["Ct"], p["info_o"] = deflate_outliers(E, Et, outliers)
         Et = ops.transpose(E)
-    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
+    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split))
     return p
 
 
@@ -188,7 +198,7 @@ def fit_error_matrix_front_group(Es, Ets, rank, outliers, spread, M_out, E_group
         for b in range(B):
             _, p["UO"][b], p["Ct"][b], p["info_o"][b] = deflate_outliers(Es[b], Ets[b], outliers[b], out=E_group[b])
             ops.transpose(E_group[b], out=Et_group[b])
-    p["ctx"] = ops.lowrank_fit_front(E_group, Et_group, rf, over, FIT_ITERS, M_out, **_fit_kwargs(spread, sketch_split))
+    p["ctx"] = ops.lowrank_fit_front(E_group, Et_group, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split))
     return p
 
 

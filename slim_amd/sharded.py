@@ -193,7 +193,7 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         Cp = ops.gemm_nt(op, op, out_f32=True)[0]
         parallel.reduce(Cp, j.owner, group)
         if rank == j.owner:
-            j.P, _, j.info = ops.gramfit_iterate(Cp.to(torch.bfloat16), j.l, _lora.FIT_ITERS, seed=_lora.FIT_SEED, cond_e=j.cond)
+            j.P, _, j.info = ops.gramfit_iterate(Cp.to(torch.bfloat16), j.l, _lora.fit_iters(j.l), seed=_lora.FIT_SEED, cond_e=j.cond)
         else:
             j.P = torch.empty(j.Dm, j.l, dtype=torch.bfloat16, device=dev)
             j.info = torch.zeros(64, dtype=torch.int32, device=dev)

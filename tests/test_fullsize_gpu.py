@@ -128,3 +128,34 @@ def test_mask_and_codes_bit_exact_full_size(ops):
     fq, codes = ops.fake_quant_pt(Wm.to(DEV), sf.reshape(1), 4, want_codes=True)
     assert torch.equal(codes.cpu(), codes_ref)
     assert torch.equal(fq.cpu(), O.dequantize_per_tensor(codes_ref, sf_ref).to(torch.bfloat16))
+
+
+def _optimum_from_gram(E, rank):
+    """sqrt(sum_{i > r} sigma_i^2) from the eigenvalues of the fp64 Gram matrix on the short side (an SVD of a matrix
+    this size takes minutes): tail sum = trace - sum of the r largest eigenvalues."""
+    Ed = E.double()
+    G = Ed @ Ed.t() if E.shape[0] <= E.shape[1] else Ed.t() @ Ed
+    ev = torch.linalg.eigvalsh(G)
+    return float(torch.sqrt(ev[:ev.numel() - rank].clamp_min(0).sum())), float(torch.sqrt(ev[-1] / ev[-rank]))
+
+
+@pytest.mark.parametrize("N,K,rank", [(28672, 8192, 1024), (8192, 28672, 1024)])
+def test_fit_within_1e3_at_llama3_70b_mlp_shapes(ops, N, K, rank):
+    """The up/gate and down projections of a LLaMA-3-70B-shaped block (8192 x 28672, adapters of rank 1024 = 10 % padded
+    to the 256-tile, eigenproblem of size 1152): the product path of the fit against the optimum of slim/lora.py:172-185."""
+    from slim_amd.lora import fit_error_matrix, outlier_columns
+    E, sr = _error_matrix(ops, N, K, 300 + N % 97)
+    outl, spread = outlier_columns(sr, rank=rank)
+    U, Ut, L, info = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread)
+    assert int(info[:-1].abs().sum()) == 0
+    opt, cond = _optimum_from_gram(E, rank)
+    # the error in fp64 by blocks of rows (the full fp32 difference matrix would be 0.9 GB, fine, but fp64 keeps the sum exact)
+    err2 = 0.0
+    Uf, Lf = U[:, :rank].double(), L[:, :rank].double()
+    for r0 in range(0, N, 4096):
+        D = E[r0:r0 + 4096].double() - Uf[r0:r0 + 4096] @ Lf.t()
+        err2 += float((D * D).sum())
+    excess = err2 ** 0.5 / opt - 1
+    print(f"{N}x{K} r={rank}: sigma_1/sigma_r {cond:.1f}, deflated {0 if outl is None else outl[1]}, "
+          f"excess over the truncated SVD {excess:+.2e}")
+    assert excess <= 1e-3, excess
