@@ -202,6 +202,9 @@ def main():
     from slim_amd.quantization.quantization import Quantizer
 
     packed = {}
+    # as in the driver, where the fits of a block are sized from what the same linears of the previous block measured: here
+    # the previous step's block (the set-up steps before the warm-up fill the dictionary)
+    level_hints = {}
     recipe = dict(sparsity_ratio=0.5, lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=256)
 
     def step_layers(n_streams=None):
@@ -220,7 +223,7 @@ def main():
         # the per-linear body of slim_amd.prune.prune_wanda after the statistics pass
         compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in mine], dev, 2, 4,
                          quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
-                         n_streams=args.streams if n_streams is None else n_streams, **recipe)
+                         n_streams=args.streams if n_streams is None else n_streams, level_hints=level_hints, **recipe)
         # pack: the compressed weight in its 2:4 4-bit storage form (0.375 byte per element); the status words are read
         # after the timed region
         for i in mine:

@@ -24,11 +24,17 @@ extern "C" {
 
 #define SLIM_HIP_ABI_VERSION 1
 #define SLIM_FIT_INFO_WORDS 64
-/* info_out of the fits: words 0 .. 62 are status words of solver / orthonormalisation steps (0 = fine).  Word 63 is not
+/* info_out of the fits: words 0 .. 61 are status words of solver / orthonormalisation steps (0 = fine).  Word 63 is not
  * an error: 0, or -- when the singular values of E inside the fitted subspace turned out to be spread over more than the
- * 2^ns_steps the orthonormalisations were sized for -- the ns_steps value that covers them; the fit should then be
- * repeated with it (its result may have lost accuracy in the weakest directions). */
+ * orthonormalisations were sized for -- the ns_steps value (bits 0-7, no bits 8-15) that covers them; the fit should then
+ * be repeated with it (its result may have lost accuracy in the weakest directions). */
 #define SLIM_FIT_INFO_COND_WORD 63
+/* Word 62 is not an error either: ceil(4 log2(largest / weakest eigenvalue that matters)) of the Gram matrix inside the
+ * fitted subspace, as the fit found it.  A caller that fits a similar matrix next (the same linear of the next decoder
+ * block) may pass ceil(word / 4 + 1) in bits 8-15 of ns_steps: the orthonormalisations after the first are then sized for
+ * that measured spread instead of the a-priori estimate in bits 0-7, which usually saves one or two Newton-Schulz steps
+ * each; word 63 reports when the hint was too low. */
+#define SLIM_FIT_INFO_LEVEL_WORD 62
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_TWO_SIDED 2    /* alternating subspace iteration on E and E^T (two products with the N x K matrix and two
                                  * orthonormalisations per iteration) instead of the iteration on the Gram matrix of E */
@@ -248,9 +254,9 @@ int slim_orthonormalize_bf16(const void* X, const void* Xt, int64_t rows, int l,
  *   E [N, K], Et [K, N] bf16;  outputs U [N, r], Ut [r, N] (= lora_right, may be NULL),
  *   L [K, r] (= lora_left), S fp32 [r] (may be NULL), info_out int32 [SLIM_FIT_INFO_WORDS]
  *   (rocSOLVER status words, all zero on success; may be NULL).
- *   flags: SLIM_FIT_*; ns_steps: log2 of the conditioning (largest / smallest singular value of an iterate inside the
+ *   flags: SLIM_FIT_*; ns_steps bits 0-7: log2 of the conditioning (largest / smallest singular value of E inside the
  *   subspace) the Newton-Schulz orthonormalisations are sized for, 1 .. 12 (0 = 9): it selects the coefficient schedule
- *   and the number of steps. */
+ *   and the number of steps; bits 8-15 (optional): see SLIM_FIT_INFO_LEVEL_WORD. */
 int64_t slim_lowrank_fit_workspace_bytes(int64_t N, int64_t K, int64_t l);
 int slim_lowrank_fit(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter, uint32_t seed,
                      int flags, int ns_steps, const float* s, void* U, void* Ut, void* L, float* S, int32_t* info_out,
@@ -284,6 +290,23 @@ int slim_lowrank_fit_back_batched(int batch, int64_t N, int64_t K, int r, int l,
                                   const float* vecs, const float* evals, const int32_t* eig_info, const float* s, void* U,
                                   void* Ut, void* L, float* S, int32_t* info_out, void* workspace, int64_t workspace_bytes,
                                   void* stream);
+
+/* The two halves for a lockstep group of fits whose shapes differ but whose short dimension Dm = min(N, K), l and r agree
+ * (all seven linears of a LLaMA-2-7B block: 4096 x 4096, 11008 x 4096, 4096 x 11008).  No reference counterpart (one
+ * torch.svd per layer, slim/lora.py:172).  The Gram-side subspace iteration sees only the Dm x Dm matrix, so it runs as ONE
+ * batched chain; what touches the N x K matrices runs member by member; every member's result is bit-identical to
+ * slim_lowrank_fit_front / _back on it alone.  E, Et, s, U, Ut, L: HOST arrays of `batch` device pointers (s, or single
+ * entries of it, may be NULL); Ns, Ks: host arrays of the shapes; M_out / vecs [batch][l, l], evals [batch][l], eig_info
+ * [batch] or NULL, S [batch][r] or NULL, info_out [batch][SLIM_FIT_INFO_WORDS].  flags: SLIM_FIT_NO_SKETCH_SPLIT only
+ * (the other modes do not run as a mixed-shape group). */
+int64_t slim_lowrank_fit_group_workspace_bytes(const int64_t* Ns, const int64_t* Ks, int batch, int64_t l);
+int slim_lowrank_fit_front_group(const void* const* E, const void* const* Et, const int64_t* Ns, const int64_t* Ks, int batch,
+                                 int r, int l, int n_iter, uint32_t seed, int flags, int ns_steps, float* M_out,
+                                 int32_t* state, void* workspace, int64_t workspace_bytes, void* stream);
+int slim_lowrank_fit_back_group(const int64_t* Ns, const int64_t* Ks, int batch, int r, int l, const int32_t* state,
+                                const float* vecs, const float* evals, const int32_t* eig_info, const float* const* s,
+                                void* const* U, void* const* Ut, void* const* L, float* S, int32_t* info_out, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 
 /* The pieces of the fit for a layer that several GPUs hold in shards along its long dimension (no counterpart in the
  * reference, which is single-GPU; what they compute is part of the torch.svd of slim/lora.py:172).  With Dm the short

@@ -58,6 +58,9 @@ PROTOTYPES = {
     "slim_lowrank_fit_front": (i32, [vp, vp, i64, i64, i32, i32, i32, u32, i32, i32, vp, vp, vp, i64, vp]),
     "slim_lowrank_fit_back": (i32, [i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_fit_front_batched": (i32, [vp, vp, i32, i64, i64, i32, i32, i32, u32, i32, i32, vp, vp, vp, i64, vp]),
+    "slim_lowrank_fit_group_workspace_bytes": (i64, [vp, vp, i32, i64]),
+    "slim_lowrank_fit_front_group": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, u32, i32, i32, vp, vp, vp, i64, vp]),
+    "slim_lowrank_fit_back_group": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "slim_lowrank_fit_back_batched": (i32, [i32, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "slim_tridiagonalize_f32": (i32, [vp, i32, vp, vp, vp, vp, i64, vp]),
     "slim_eigh_f32": (i32, [vp, i32, i32, vp, vp, vp, i64, vp]),

@@ -145,24 +145,32 @@ __global__ void top_eigvecs_kernel(const float* __restrict__ vecs, const float* 
 
 // After the fit: the eigenvalues of the Rayleigh-Ritz matrix are the squared singular values of E inside the subspace, so
 // their extreme ratio is the conditioning the orthonormalisations had to cope with.  When it exceeds what they were sized
-// for (2^cond_e, half a level of slack), the last status word of the problem receives the level that would have covered it
-// and the caller fits that layer again; otherwise 0.  (An application of the Gram matrix squares the conditioning, which
-// the fit allows for by itself: cond_e and the level reported are in terms of the singular values of E.)
-__global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r, int batch, int cond_e, int* __restrict__ info) {
+// for, the last status word of the problem receives the level (log2 of the ratio of singular values, rounded up) that would
+// have covered it and the caller fits that layer again; otherwise 0.  levels: the encoded conditioning levels of the fit
+// (ns_levels_*): the iteration's orthonormalisations after the first were sized for eigenvalue ratios up to 2^later when
+// later > 0 (half a level of slack), else for singular value ratios up to 2^cond_e (an application of the Gram matrix
+// squares the conditioning, which the fit allows for by itself).  Word SLIM_FIT_INFO_LEVEL_WORD receives the ratio found,
+// ceil(4 log2(largest / weakest eigenvalue that matters)): what a caller needs to size the next, similar fit.
+__global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r, int batch, int levels, int* __restrict__ info) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
+    const int cond_e = levels & 0xff, later = (levels >> 8) & 0xff;
     // ascending eigenvalues; the weakest direction that still matters sits halfway into the oversampling part
     const float hi = evals[(int64_t)b * l + l - 1], lo = evals[(int64_t)b * l + (l - r) / 2];
-    int need = 0;
+    int need = 0, found = 0;
     if (hi > 0.f) {
-        const float lg = lo > 0.f ? 0.5f * log2f(hi / lo) : 100.f;
-        if (lg > (float)cond_e + 0.5f) {
+        const float c = lo > 0.f ? log2f(hi / lo) : 200.f, lg = 0.5f * c;
+        found = (int)ceilf(4.f * c);
+        found = found < 0 ? 0 : (found > 255 ? 255 : found);
+        if (later > 0 ? c > (float)later + 0.5f : lg > (float)cond_e + 0.5f) {
             need = (int)ceilf(lg);
             if (need > NS_SCHED_MAX_E / 2) need = NS_SCHED_MAX_E / 2;
-            if (need <= cond_e) need = 0;      // already at the widest schedule
+            if (later > 0) need = need < 1 ? 1 : need;      // the repeat runs without the caller's hint
+            else if (need <= cond_e) need = 0;              // already at the widest schedule
         }
     }
-    info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_WORDS - 1] = need;
+    info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_COND_WORD] = need;
+    info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_LEVEL_WORD] = found;
 }
 
 // bf16 identity [batch][rows, l] and its transpose [batch][l, rows] (rows == l)
@@ -586,6 +594,17 @@ static int ns_orth(Pair* bufs, int cur, int64_t rows, int l, const NsStep* steps
 //      k / 512 of noise -- harmless for k <= 4, ruinous for k in the hundreds.
 //   3. The minimax schedule for what is left (kNsSchedule, rescaled for singular values up to 1.25): `enough` steps for an
 //      intermediate basis, all of them for the last basis before the Rayleigh-Ritz step.
+// The conditioning levels of a fit travel in one int (the ns_steps / cond_e arguments): bits 0-7 = log2 of the ratio of
+// singular values of E inside the subspace that the orthonormalisations must cover, as the caller estimates it beforehand
+// (0: the default, 9); bits 8-15 (optional) = log2 of the ratio of EIGENVALUES of the Gram matrix inside the subspace as a
+// similar fit measured it (status word SLIM_FIT_INFO_LEVEL_WORD): the Gram-side iteration then sizes its
+// orthonormalisations after the first for that, the first (a random start) stays on the estimate.
+static inline int ns_levels_clamped(int ns_steps) {
+    int cond = ns_steps & 0xff, later = (ns_steps >> 8) & 0xff;
+    cond = cond > 0 ? (cond > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : cond) : 9;
+    later = later > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : later;
+    return cond | (later << 8);
+}
 #define NS_MAX_STEPS 24
 static int build_ns_steps(int cond_e, bool final_pass, NsStep* out) {
     const NsStep fixed{3.4445f, -4.7750f, 2.0315f};
@@ -699,7 +718,7 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     if (phase != FIT_BACK) SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
     if (phase == FIT_BACK ? (*state & FIT_STATE_GRAM) != 0 : !(flags & (SLIM_FIT_TWO_SIDED | SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL))) {
         int inner = state ? (*state & ~FIT_STATE_GRAM) : 0;
-        const int cond = ns_steps > 0 ? (ns_steps > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : ns_steps) : 9;
+        const int cond = ns_levels_clamped(ns_steps);
         int rc = gram_fit_impl(phase, E, Et, batch, N, K, r, l, n_iter, seed, flags, cond, s, U, Ut, L, S, info_out, w, stream, M_ext,
                                &inner, ext_vecs, ext_evals, ext_info);
         if (rc == SLIM_OK && phase == FIT_FRONT) *state = inner | FIT_STATE_GRAM;
@@ -715,7 +734,7 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     if (flags & SLIM_FIT_NO_SKETCH_SPLIT) w.gram_cap = GRAM_SPLITS_SHARED_CHIP;
     int ninfo = 0, a = 0, b = 0;
     // ns_steps: log2 of the conditioning the orthonormalisations must cover (0: 2^9)
-    const int nq = ns_steps > 0 ? (ns_steps > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : ns_steps) : 9;
+    const int nq = ns_levels_clamped(ns_steps) & 0xff;
     // when the subspace is the whole space the basis must be orthonormal to working precision in every
     // direction, however weak: take the exact factorisation
     if (l == N || l == K) flags |= SLIM_FIT_CHOLESKY_QR;
@@ -820,8 +839,9 @@ static int gram_iterate(Pair* Pb, const bf16_t* C16, int64_t sC, int batch, int6
                         int flags, int cond_e, FitWs& w, float* sk_slab, int64_t sSk, void* stream, int* a_out, int* ninfo) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t sP = Dm * l;
-    // an application of C squares the conditioning inside the subspace
-    const int e2 = 2 * cond_e > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : 2 * cond_e;
+    // cond_e: encoded levels (ns_levels_clamped).  An application of C squares the conditioning inside the subspace
+    const int est = 2 * (cond_e & 0xff) > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : 2 * (cond_e & 0xff);
+    const int later = (cond_e >> 8) & 0xff ? (cond_e >> 8) & 0xff : est;
     const int64_t n = (int64_t)l * Dm;
     randn_bf16_kernel<<<dim3((unsigned)ceil_div64(n, 256), (unsigned)batch), 256, 0, st>>>(Pb[1].Xt, n, seed, sP);
     SLIM_LAUNCH_CHECK();
@@ -831,7 +851,7 @@ static int gram_iterate(Pair* Pb, const bf16_t* C16, int64_t sC, int batch, int6
         const int dst = (src + 1) % 3;
         CHK(nt(batch, Pb[src].Xt, Dm, sP, C16, Dm, sC, l, (int)Dm, (int)Dm, nullptr, Pb[dst].Xt, Dm, Pb[dst].X, l, stream, sk_slab,
                sSk));
-        CHK(orth(Pb, dst, Dm, l, it == n_iter, flags, e2, w, *ninfo, stream, &a));
+        CHK(orth(Pb, dst, Dm, l, it == n_iter, flags, it == 0 ? est : later, w, *ninfo, stream, &a));
         *ninfo += 2;
         src = a;
     }
@@ -895,15 +915,15 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
         if (phase == FIT_FRONT) {
             SLIM_REQUIRE(M_ext && state, "slim_lowrank_fit_front: bad arguments");
             SLIM_HIP(hipMemcpyAsync(M_ext, w.G, (size_t)batch * sG * sizeof(float), hipMemcpyDeviceToDevice, st));
-            *state = a | (ninfo << 8) | (cond_e << 16);
+            *state = a | (ninfo << 8) | ((cond_e & 0xff) << 16) | (((cond_e >> 8) & 0x3f) << 24);
             return SLIM_OK;
         }
     } else {
         SLIM_REQUIRE(state && ext_vecs && ext_evals, "slim_lowrank_fit_back: bad arguments");
         a = *state & 0xff;
         ninfo = (*state >> 8) & 0xff;
-        cond_e = (*state >> 16) & 0xff;
-        SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS - 1, "slim_lowrank_fit_back: bad state");
+        cond_e = ((*state >> 16) & 0xff) | (((*state >> 24) & 0x3f) << 8);
+        SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS - 2, "slim_lowrank_fit_back: bad state");
         if (ext_info) {
             info_scatter_kernel<<<(batch + 63) / 64, 64, 0, st>>>(ext_info, batch, w.info, ninfo);
             SLIM_LAUNCH_CHECK();
@@ -1043,7 +1063,7 @@ extern "C" int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_it
     hipStream_t st = (hipStream_t)stream;
     FitWs w = fit_ws((char*)workspace, 1, Dm, 8, l);
     SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
-    const int cond = cond_e > 0 ? (cond_e > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : cond_e) : 9;
+    const int cond = ns_levels_clamped(cond_e);
     int a = 0, ninfo = 0;
     CHK(gram_iterate(w.A, (const bf16_t*)C16, Dm * Dm, 1, Dm, l, n_iter, seed, flags & ~(SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL),
                      cond, w, w.sketch_slab, (int64_t)SKETCH_MAX_SPLITS * l * Dm, stream, &a, &ninfo));
@@ -1090,7 +1110,7 @@ extern "C" int slim_gramfit_factors(int right, const void* P, const void* Z, int
     bf16_t* T16b = (bf16_t*)((char*)workspace + al256((int64_t)l * l * 2));
     const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, 1);
     if (info) {     // the conditioning the spectrum shows against the level the iteration was sized for -> last status word
-        cond_check_kernel<<<1, 64, 0, st>>>(evals, l, r, 1, cond_e > 0 ? cond_e : 9, info);
+        cond_check_kernel<<<1, 64, 0, st>>>(evals, l, r, 1, ns_levels_clamped(cond_e), info);
         SLIM_LAUNCH_CHECK();
     }
     if (right) {
@@ -1138,6 +1158,151 @@ extern "C" int slim_lowrank_fit_back_batched(int batch, int64_t N, int64_t K, in
     return fit_impl(FIT_BACK, nullptr, nullptr, batch, N, K, r, l, n_iter, 0, 0, 0, s, U, Ut, L, S, info_out, workspace,
                     workspace_bytes, stream, nullptr, &st_copy, vecs, evals, eig_info);
 }
+// ---- lockstep group of fits with different shapes -----------------------------------------------------------------------
+// The subspace iteration of the Gram-side fit sees only the Dm x Dm matrix C, Dm = min(N, K): fits of layers with different
+// shapes but the same Dm, l and r (all seven linears of a LLaMA block: 4096 x 4096, 11008 x 4096, 4096 x 11008) run it as ONE
+// batched chain.  What touches the N x K matrices (C itself, the projection Z, the factors) runs member by member between the
+// batched parts; every member's arithmetic is that of slim_lowrank_fit_front / _back on it alone, so the results are
+// bit-identical to single fits.  E / Et / U / Ut / L / s: host arrays of `batch` device pointers; Ns / Ks: host arrays of
+// the shapes.  The workspace is that of a batch of Dx_max x Dm problems, Dx_max the largest max(N, K).
+static int group_dims(const int64_t* Ns, const int64_t* Ks, int batch, int64_t* Dm_out, int64_t* Dx_max_out) {
+    SLIM_REQUIRE(Ns && Ks && batch >= 1 && batch <= 1024, "slim_lowrank_fit_group: bad batch arguments");
+    int64_t Dm = 0, Dx_max = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int64_t mn = Ns[b] < Ks[b] ? Ns[b] : Ks[b], mx = Ns[b] < Ks[b] ? Ks[b] : Ns[b];
+        SLIM_REQUIRE(mn > 0 && Ns[b] % 8 == 0 && Ks[b] % 8 == 0, "slim_lowrank_fit_group: N, K must be positive multiples of 8");
+        SLIM_REQUIRE(b == 0 || mn == Dm, "slim_lowrank_fit_group: the members must share min(N, K)");
+        Dm = mn;
+        Dx_max = mx > Dx_max ? mx : Dx_max;
+    }
+    *Dm_out = Dm;
+    *Dx_max_out = Dx_max;
+    return SLIM_OK;
+}
+
+extern "C" int64_t slim_lowrank_fit_group_workspace_bytes(const int64_t* Ns, const int64_t* Ks, int batch, int64_t l) {
+    int64_t Dm = 0, Dx = 0;
+    if (l <= 0 || group_dims(Ns, Ks, batch, &Dm, &Dx) != SLIM_OK) return 0;
+    return fit_ws(nullptr, batch, Dx, Dm, l).total;
+}
+
+// the batched workspace as member b alone sees it (the buffers the per-member products use)
+static FitWs member_ws(const FitWs& w, int b, int64_t l) {
+    FitWs m = w;
+    const int64_t sG = l * l;
+    m.batch = 1;
+    m.G = w.G + b * sG;
+    m.G2 = w.G2 + b * sG;
+    m.G16 = w.G16 + b * sG;
+    m.T16 = w.T16 + b * sG;
+    m.T16b = w.T16b + b * sG;
+    m.slab = w.slab + (int64_t)b * GRAM_MAX_SPLITS * sG;
+    m.info = w.info + b * SLIM_FIT_INFO_WORDS;
+    return m;
+}
+
+extern "C" int slim_lowrank_fit_front_group(const void* const* E, const void* const* Et, const int64_t* Ns, const int64_t* Ks,
+                                            int batch, int r, int l, int n_iter, uint32_t seed, int flags, int ns_steps,
+                                            float* M_out, int32_t* state, void* workspace, int64_t workspace_bytes,
+                                            void* stream) {
+    int64_t Dm = 0, Dxm = 0;
+    CHK(group_dims(Ns, Ks, batch, &Dm, &Dxm));
+    SLIM_REQUIRE(E && Et && M_out && state && workspace, "slim_lowrank_fit_front_group: null pointer");
+    SLIM_REQUIRE(r > 0 && l >= r && l < Dm && l % 8 == 0 && r % 8 == 0 && n_iter >= 0, "slim_lowrank_fit_front_group: bad sizes");
+    SLIM_REQUIRE(2 * (n_iter + 1) + 1 <= SLIM_FIT_INFO_WORDS / 2, "slim_lowrank_fit_front_group: too many iterations");
+    SLIM_REQUIRE(!(flags & (SLIM_FIT_TWO_SIDED | SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL)),
+                 "slim_lowrank_fit_front_group: only the Gram-side iteration runs as a mixed-shape group");
+    SLIM_REQUIRE(workspace_bytes >= fit_ws(nullptr, batch, Dxm, Dm, l).total, "slim_lowrank_fit_front_group: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    FitWs w = fit_ws((char*)workspace, batch, Dxm, Dm, l);      // w.B: the iterates (Dm rows), w.A[0]: the projections
+    SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    const int cond = ns_levels_clamped(ns_steps);
+    const int64_t sP = Dm * l, sZ = Dxm * l, sG = (int64_t)l * l, sC = Dm * Dm, sSk = (int64_t)SKETCH_MAX_SPLITS * l * Dxm;
+    float* sk_slab = (flags & SLIM_FIT_NO_SKETCH_SPLIT) ? nullptr : w.sketch_slab;
+    if (flags & SLIM_FIT_NO_SKETCH_SPLIT) w.gram_cap = GRAM_SPLITS_SHARED_CHIP;
+    for (int b = 0; b < batch; ++b) {
+        SLIM_REQUIRE(E[b] && Et[b], "slim_lowrank_fit_front_group: null operand");
+        const bool right = Ks[b] <= Ns[b];
+        const int64_t Dx = right ? Ns[b] : Ks[b];
+        GemmArgs g;            // C = E^T E (operand E^T [K, N]) or E E^T (operand E [N, K])
+        g.A = g.B = (const bf16_t*)(right ? Et[b] : E[b]);
+        g.lda = g.ldb = Dx;
+        g.M = g.N = (int)Dm;
+        g.Kd = (int)Dx;
+        g.C16 = g.Ct16 = w.C16 + b * sC;
+        g.ldc16 = g.ldct = Dm;
+        g.sym = 1;
+        CHK(slim_gemm_launch(g, stream));
+    }
+    int a = 0, ninfo = 0;
+    CHK(gram_iterate(w.B, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond, w, sk_slab, sSk, stream, &a, &ninfo));
+    for (int b = 0; b < batch; ++b) {
+        const bool right = Ks[b] <= Ns[b];
+        const int64_t Dx = right ? Ns[b] : Ks[b];
+        FitWs m = member_ws(w, b, l);
+        bf16_t* Z = w.A[0].X + b * sZ;
+        bf16_t* Zt = w.A[0].Xt + b * sZ;
+        CHK(nt(1, w.B[a].Xt + b * sP, Dm, 0, (const bf16_t*)(right ? E[b] : Et[b]), Dm, 0, l, (int)Dx, (int)Dm, nullptr, Zt, Dx, Z, l,
+               stream, sk_slab ? sk_slab + b * sSk : nullptr, sSk));
+        CHK(gram(Zt, Dx, l, m, nullptr, stream));
+    }
+    SLIM_HIP(hipMemcpyAsync(M_out, w.G, (size_t)batch * sG * sizeof(float), hipMemcpyDeviceToDevice, st));
+    *state = a | (ninfo << 8) | ((cond & 0xff) << 16) | (((cond >> 8) & 0x3f) << 24) | FIT_STATE_GRAM;
+    return SLIM_OK;
+}
+
+extern "C" int slim_lowrank_fit_back_group(const int64_t* Ns, const int64_t* Ks, int batch, int r, int l, const int32_t* state,
+                                           const float* vecs, const float* evals, const int32_t* eig_info,
+                                           const float* const* s, void* const* U, void* const* Ut, void* const* L, float* S,
+                                           int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    int64_t Dm = 0, Dxm = 0;
+    CHK(group_dims(Ns, Ks, batch, &Dm, &Dxm));
+    SLIM_REQUIRE(state && vecs && evals && U && Ut && L && workspace, "slim_lowrank_fit_back_group: null pointer");
+    SLIM_REQUIRE(r > 0 && l >= r && l < Dm && l % 8 == 0 && r % 8 == 0, "slim_lowrank_fit_back_group: bad sizes");
+    SLIM_REQUIRE(workspace_bytes >= fit_ws(nullptr, batch, Dxm, Dm, l).total, "slim_lowrank_fit_back_group: workspace too small");
+    SLIM_REQUIRE(*state & FIT_STATE_GRAM, "slim_lowrank_fit_back_group: bad state");
+    hipStream_t st = (hipStream_t)stream;
+    FitWs w = fit_ws((char*)workspace, batch, Dxm, Dm, l);
+    const int inner = *state & ~FIT_STATE_GRAM;
+    const int a = inner & 0xff, cond_e = ((inner >> 16) & 0xff) | (((inner >> 24) & 0x3f) << 8);
+    int ninfo = (inner >> 8) & 0xff;
+    SLIM_REQUIRE(a >= 0 && a < 3 && ninfo >= 0 && ninfo < SLIM_FIT_INFO_WORDS - 2, "slim_lowrank_fit_back_group: bad state");
+    if (eig_info) {
+        info_scatter_kernel<<<(batch + 63) / 64, 64, 0, st>>>(eig_info, batch, w.info, ninfo);
+        SLIM_LAUNCH_CHECK();
+    }
+    ninfo += 1;
+    cond_check_kernel<<<(batch + 63) / 64, 64, 0, st>>>(evals, l, r, batch, cond_e, w.info);
+    SLIM_LAUNCH_CHECK();
+    const int64_t sP = Dm * l, sZ = Dxm * l, sG = (int64_t)l * l;
+    const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, 1);
+    for (int b = 0; b < batch; ++b) {
+        SLIM_REQUIRE(U[b] && Ut[b] && L[b], "slim_lowrank_fit_back_group: null output");
+        const int64_t N = Ns[b], K = Ks[b];
+        const bool right = K <= N;
+        const bf16_t* P = w.B[a].X + b * sP;
+        const bf16_t* Z = w.A[0].X + b * sZ;
+        bf16_t* T16 = w.T16 + b * sG;
+        bf16_t* T16b = w.T16b + b * sG;
+        float* Sb = S ? S + (int64_t)b * r : nullptr;
+        if (right) {        // U = Z (W S^-1), L = P (W S)
+            top_eigvecs_kernel<<<grid, 256, 0, st>>>(vecs + b * sG, evals + (int64_t)b * l, l, r, nullptr, Sb, T16, T16b);
+            SLIM_LAUNCH_CHECK();
+            CHK(nt(1, P, l, 0, T16b, l, 0, (int)K, r, l, nullptr, (bf16_t*)L[b], r, nullptr, 0, stream));
+            CHK(nt(1, Z, l, 0, T16, l, 0, (int)N, r, l, nullptr, (bf16_t*)U[b], r, (bf16_t*)Ut[b], N, stream));
+        } else {            // U = P W, L = Z W
+            top_eigvecs_kernel<<<grid, 256, 0, st>>>(vecs + b * sG, evals + (int64_t)b * l, l, r, T16, Sb, nullptr, nullptr);
+            SLIM_LAUNCH_CHECK();
+            CHK(nt(1, Z, l, 0, T16, l, 0, (int)K, r, l, nullptr, (bf16_t*)L[b], r, nullptr, 0, stream));
+            CHK(nt(1, P, l, 0, T16, l, 0, (int)N, r, l, nullptr, (bf16_t*)U[b], r, (bf16_t*)Ut[b], N, stream));
+        }
+        if (s && s[b]) CHK(scale_rows_batched(L[b], s[b], K, r, 1, stream));
+    }
+    if (info_out)
+        SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return SLIM_OK;
+}
+
 extern "C" int slim_lowrank_fit_front(const void* E, const void* Et, int64_t N, int64_t K, int r, int l, int n_iter,
                                       uint32_t seed, int flags, int ns_steps, float* M_out, int32_t* state, void* workspace,
                                       int64_t workspace_bytes, void* stream) {

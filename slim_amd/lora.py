@@ -41,18 +41,35 @@ FIT_EXACT_FINAL = os.environ.get("SLIM_FIT_EXACT_FINAL", "0") == "1"
 FIT_SKETCH_SPLIT = os.environ.get("SLIM_FIT_SKETCH_SPLIT", "1") == "1"
 
 
-def fit_ns_steps(spread):
-    """log2 of the conditioning the fit's Newton-Schulz orthonormalisations are sized for (the `ns_steps` argument of
-    slim_lowrank_fit), from the spread max(s) / median(s) of the saliency scales that are left after the outlier columns
+def fit_ns_steps(spread, hint=0):
+    """The `ns_steps` argument of slim_lowrank_fit.  Bits 0-7: log2 of the conditioning the fit's Newton-Schulz
+    orthonormalisations are sized for, from the spread max(s) / median(s) of the saliency scales that are left after the outlier columns
     have been split off.  The error matrix is (benign matrix) x diag(s): its largest singular values come from the columns
     with the largest scale, the bulk from the typical ones, so the conditioning of an iterate inside the leading subspace
     is of the order of the spread (measured: about a third of it, so half the spread is assumed).  The fit checks the
     assumption against the spectrum it finds (status word SLIM_FIT_INFO_COND_WORD) and the driver repeats a fit whose
-    estimate was too low with FIT_COND_FLOOR raised (prune.compress_linears)."""
+    estimate was too low with FIT_COND_FLOOR raised (prune.compress_linears).
+    Bits 8-15: `hint`, the level a similar fit measured (level_hint_from_status), or 0; ignored while FIT_COND_FLOOR is
+    raised (a repeated fit runs on the estimate alone)."""
     import math
     if os.environ.get("SLIM_FIT_COND_E"):          # tuning aid: fixed value
         return int(os.environ["SLIM_FIT_COND_E"])
-    return int(min(6, max(1, FIT_COND_FLOOR, math.ceil(math.log2(max(float(spread) / 2.0, 1.0))))))
+    level = int(min(6, max(1, FIT_COND_FLOOR, math.ceil(math.log2(max(float(spread) / 2.0, 1.0))))))
+    if hint and not FIT_COND_FLOOR and FIT_LEVEL_HINTS:
+        level |= int(min(12, max(2, hint))) << 8
+    return level
+
+
+# SLIM_FIT_LEVEL_HINTS=0: the driver does not size a block's fits from what the same linears of the previous block measured
+FIT_LEVEL_HINTS = os.environ.get("SLIM_FIT_LEVEL_HINTS", "1") == "1"
+
+
+def level_hint_from_status(word):
+    """The hint for the next similar fit from status word SLIM_FIT_INFO_LEVEL_WORD of a finished one (0: none): the
+    measured log2 spread of the Gram matrix's eigenvalues inside the subspace plus one level, because the subspaces of the
+    iterations before the last are not converged and a little worse conditioned."""
+    import math
+    return int(math.ceil(word / 4.0 + 1.0)) if word > 0 else 0
 
 
 # lower bound of fit_ns_steps; raised by the driver while it repeats fits whose conditioning was underestimated
@@ -118,7 +135,7 @@ def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, i
     return U, ops.transpose(U), L, torch.cat([info_o, fit_info])
 
 
-def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
+def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
     """Rank-`rank` factors of the error matrix E [N, K] (Et its transpose): U [N, r8], Ut [r8, N], L [K, r8]
     with r8 = rank rounded up to a multiple of 8 and the columns >= rank zero (the MFMA products that consume
     the factors need a reduction length that is a multiple of 8; callers slice [:, :rank] for the adapters).
@@ -138,15 +155,15 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0):
         E, UO, Ct, info_o = deflate_outliers(E, Et, outliers)
         Et = ops.transpose(E)
     fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
-                          ns_steps=fit_ns_steps(spread), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
+                          ns_steps=fit_ns_steps(spread, hint), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
                           sketch_split=FIT_SKETCH_SPLIT)
     return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
 
 
-def _fit_kwargs(spread, sketch_split=True):
+def _fit_kwargs(spread, sketch_split=True, hint=0):
     return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL,
                                                     FIT_SKETCH_SPLIT and sketch_split),
-                ns_steps=fit_ns_steps(spread))
+                ns_steps=fit_ns_steps(spread, hint))
 
 
 def fit_plan(N, K, rank, outliers=None):
@@ -162,7 +179,7 @@ def fit_plan(N, K, rank, outliers=None):
     return rf, over, ops.fit_subspace(N, K, rf, over), t
 
 
-def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=True):
+def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None):
     """fit_error_matrix up to the Rayleigh-Ritz matrix of its randomized fit (written to M_out [l, l], l from fit_plan), so
     that the eigenproblems of several layers can share one batched tridiagonalisation.  Returns the state that
     fit_error_matrix_back completes."""
@@ -172,43 +189,53 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
         raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
     p = dict(N=N, K=K, rank=rank, t=t, UO=None, Ct=None, info_o=None)
     if t:
-        E, p["UO"], p["Ct"], p["info_o"] = deflate_outliers(E, Et, outliers)
-        Et = ops.transpose(E)
-    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split))
+        E, Et, p["UO"], p["Ct"], p["info_o"] = deflated if deflated is not None else deflated_pair(E, Et, outliers)
+    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split, hint))
     return p
 
 
-def fit_error_matrix_front_group(Es, Ets, rank, outliers, spread, M_out, E_group, Et_group, sketch_split=True):
-    """fit_error_matrix_front for B same-shape layers in lockstep: Es / Ets are the layers' error matrices, outliers their
-    deflation sets (all with the same number of real outliers t), M_out [B, l, l].  E_group [B, N, K] / Et_group
-    [B, K, N] are the strided operands of the batched fit: with t == 0 they ARE the error matrices (Es[b] is E_group[b]),
-    otherwise they receive the deflated matrices.  Every member's result equals that of fit_error_matrix_front alone."""
+def deflated_pair(E, Et, outliers):
+    """(E', E'^T, Q_O, C^T, status words) of deflate_outliers: what the fit of a layer with outlier columns starts from."""
+    E2, UO, Ct, info_o = deflate_outliers(E, Et, outliers)
+    return E2, ops.transpose(E2), UO, Ct, info_o
+
+
+def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None):
+    """fit_error_matrix_front for B layers in lockstep.  Their shapes, ranks and deflation sets may differ as long as the
+    short dimension min(N, K) and the fit's plan (rank asked of the randomized fit, oversampling, subspace dimension, see
+    fit_plan) agree: the subspace iteration then runs as one batched chain.  M_out [B, l, l].  Every member's result
+    equals that of fit_error_matrix_front alone.  deflated (optional): per layer the result of deflated_pair when the caller
+    has split the outlier columns off already, else None."""
     B = len(Es)
-    N, K = Es[0].shape
-    rf, over, l, t = fit_plan(N, K, rank, outliers[0])
-    if any(fit_plan(N, K, rank, o)[3] != t for o in outliers):
-        raise ValueError("the layers of a group must deflate the same number of outlier columns")
-    if t == 0 and rf != _round_up8(rank):
-        raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
-    p = dict(N=N, K=K, rank=rank, t=t, B=B, UO=[None] * B, Ct=[None] * B, info_o=[None] * B)
-    if t == 0:
-        if any(Es[b].data_ptr() != E_group[b].data_ptr() or Ets[b].data_ptr() != Et_group[b].data_ptr() for b in range(B)):
-            raise ValueError("without deflation the error matrices must sit in the group's strided buffers")
-    else:
-        for b in range(B):
-            _, p["UO"][b], p["Ct"][b], p["info_o"][b] = deflate_outliers(Es[b], Ets[b], outliers[b], out=E_group[b])
-            ops.transpose(E_group[b], out=Et_group[b])
-    p["ctx"] = ops.lowrank_fit_front(E_group, Et_group, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split))
+    plans = [fit_plan(E.shape[0], E.shape[1], rank, o) for E, rank, o in zip(Es, ranks, outliers)]
+    rf, over, l = plans[0][:3]
+    if any(pl[:3] != (rf, over, l) for pl in plans) or any(min(E.shape) != min(Es[0].shape) for E in Es):
+        raise ValueError("the layers of a group must share their short dimension and the plan of their fit")
+    p = dict(B=B, members=[])
+    Eds, Etds = [], []
+    for b in range(B):
+        N, K = Es[b].shape
+        t = plans[b][3]
+        if t == 0 and rf != _round_up8(ranks[b]):
+            raise NotImplementedError(f"rank {ranks[b]} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
+        m = dict(N=N, K=K, rank=ranks[b], t=t, UO=None, Ct=None, info_o=None)
+        E, Et = Es[b], Ets[b]
+        if t:
+            have = deflated[b] if deflated is not None else None
+            E, Et, m["UO"], m["Ct"], m["info_o"] = have if have is not None else deflated_pair(E, Et, outliers[b])
+        Eds.append(E)
+        Etds.append(Et)
+        p["members"].append(m)
+    p["ctx"] = ops.lowrank_fit_front_group(Eds, Etds, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split, hint))
     return p
 
 
 def fit_error_matrix_back_group(p, d, e, Q, vecs, ss, tail_info=None):
     """Second half for a group: d, e [B, l], Q, vecs [B, l, l]; ss = per-layer scale vectors (or None).  Returns one
     (U, Ut, L, info) per layer, as fit_error_matrix_back does.  tail_info: see ops.lowrank_fit_back."""
-    s = torch.stack(ss).contiguous() if ss is not None else None
-    fit = ops.lowrank_fit_back(p["ctx"], d, e, Q, vecs, s=s, tail_info=tail_info)
-    return [_assemble(p["N"], p["K"], p["rank"], p["t"], ss[b] if ss is not None else None, fit["U"][b], fit["Ut"][b],
-                      fit["L"][b], fit["info"][b], p["UO"][b], p["Ct"][b], p["info_o"][b]) for b in range(p["B"])]
+    fits = ops.lowrank_fit_back_group(p["ctx"], d, e, Q, vecs, ss, tail_info)
+    return [_assemble(m["N"], m["K"], m["rank"], m["t"], ss[b] if ss is not None else None, f["U"], f["Ut"], f["L"], f["info"],
+                      m["UO"], m["Ct"], m["info_o"]) for b, (m, f) in enumerate(zip(p["members"], fits))]
 
 
 def fit_error_matrix_back(p, d, e, Q, vecs, s, tail_info=None):
@@ -286,6 +313,8 @@ class LoraContext:
         out = [self.W, self.W_mask, self.s, self.E, self.Et]
         if getattr(self, "fit", None) is not None:
             out += list(self.fit)
+        if getattr(self, "deflated", None) is not None:
+            out += list(self.deflated)
         if self.outliers is not None:
             out.append(self.outliers[0])
         return [t for t in out if isinstance(t, torch.Tensor)]
@@ -374,8 +403,18 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     else:
         outliers, spread = None, 1.0
     c.outliers, c.spread = outliers, spread
+    c.level_hint = int(getattr(activations, "fit_level_hint", 0) or 0)
     c.fit = None
+    c.deflated = None
     return c
+
+
+def add_lora_deflate(c):
+    """Between the first and the second phase, optional: split the outlier columns of the error matrix off now (the fit's
+    front half does it otherwise), so that a driver can run this host-heavy step of its layers side by side."""
+    N, K = c.E.shape
+    if fit_plan(N, K, c.rank, c.outliers)[3]:
+        c.deflated = deflated_pair(c.E, c.Et, c.outliers)
 
 
 def planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations):
@@ -390,36 +429,40 @@ def planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations):
 
 def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations):
     """(key, l) of a layer before it is prepared: layers with equal keys can run their fits in lockstep around the shared
-    eigen-solver (same shape, rank, number of deflated outlier columns and Newton-Schulz depth), l is the size of the
-    eigenproblem; None when the shared eigen-solver does not take the layer."""
+    eigen-solver (same short dimension, same plan of the randomized fit, same Newton-Schulz depth -- the shapes themselves
+    may differ), l is the size of the eigenproblem; None when the shared eigen-solver does not take the layer."""
     l = planned_fit_l(module, rank_ratio, lora_tile_size, slim_lora, activations)
     if l is None:
         return None
     N, K = module.weight.shape
     rank = min(lora_rank((N, K), rank_ratio, lora_tile_size), min(N, K))
     use_slim = bool(slim_lora) and not activations.has_zero
-    t = fit_plan(N, K, rank, activations.outliers if use_slim else None)[3]
+    rf, over, _, t = fit_plan(N, K, rank, activations.outliers if use_slim else None)
     spread = activations.scale_spread if use_slim else 1.0
-    return ((N, K), rank, use_slim, t, fit_ns_steps(spread)), l
+    if FIT_CHOLESKY_QR or FIT_EXACT_FINAL or (t == 0 and rf != _round_up8(rank)):
+        return ("alone", id(module)), l            # modes and ranks that do not run as a mixed-shape group
+    shape = (N, K) if os.environ.get("SLIM_GROUP_BY_SHAPE", "0") == "1" else None
+    hint = int(getattr(activations, "fit_level_hint", 0) or 0)
+    return (min(N, K), rf, over, fit_ns_steps(spread, hint), shape), l
 
 
-def add_lora_fit_front_group(ctxs, M_out, E_group, Et_group, sketch_split=True):
+def add_lora_fit_front_group(ctxs, M_out, sketch_split=True):
     """Second phase, first half, for a group of layers with equal planned_fit_group keys (see
     fit_error_matrix_front_group)."""
     for c in ctxs:
         c.touch()
-    if len({fit_ns_steps(c.spread) for c in ctxs}) != 1 or len({c.rank for c in ctxs}) != 1:
-        raise ValueError("the layers of a group must share rank and Newton-Schulz depth")
-    ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], ctxs[0].rank,
-                                                   [c.outliers for c in ctxs], ctxs[0].spread, M_out, E_group, Et_group,
-                                                   sketch_split)
+    if len({fit_ns_steps(c.spread, c.level_hint) for c in ctxs}) != 1:
+        raise ValueError("the layers of a group must share their Newton-Schulz depth")
+    ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], [c.rank for c in ctxs],
+                                                   [c.outliers for c in ctxs], ctxs[0].spread, M_out, sketch_split,
+                                                   ctxs[0].level_hint, [c.deflated for c in ctxs])
 
 
 def add_lora_fit_back_group(ctxs, d, e, Q, vecs, tail_info=None):
     """Second phase, second half, for the group add_lora_fit_front_group started."""
     for c in ctxs:
         c.touch()
-    ss = [c.s for c in ctxs] if (ctxs[0].separate and ctxs[0].s is not None) else None
+    ss = [c.s if c.separate else None for c in ctxs]
     fits = fit_error_matrix_back_group(ctxs[0].pending, d, e, Q, vecs, ss, tail_info)
     ctxs[0].pending = None
     for c, f in zip(ctxs, fits):
@@ -430,7 +473,7 @@ def add_lora_fit_front(c, M_out, sketch_split=True):
     """Second phase, first half (see fit_error_matrix_front).  sketch_split=False: the caller runs several fits side by
     side, which fills the chip without cutting the sketch products along their reduction."""
     c.touch()
-    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out, sketch_split)
+    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out, sketch_split, c.level_hint, c.deflated)
 
 
 def add_lora_fit_back(c, d, e, Q, vecs, tail_info=None):
@@ -447,7 +490,7 @@ def add_lora_fit(ctxs):
         # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row); pruned
         # adapters are pruned and re-fitted before that division (lora.py:185-195)
         scaled_in_fit = c.separate and not c.prune_lora
-        c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread)
+        c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread, c.level_hint)
         if c.prune_lora:
             U, Ut, L, info = c.fit
             c.lora_left_mask = prune_and_optimize_lora(L, Ut, PRUNE_LORA_ITERS)

@@ -476,6 +476,72 @@ def lowrank_fit_back(ctx, d, e, Q, vecs, s=None, tail_info=None):
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def lowrank_fit_front_group(Es, Ets, r, oversample, n_iter, M_out, seed=0, flags=0, ns_steps=0):
+    """lowrank_fit_front for a lockstep group of matrices whose shapes may differ but whose short dimension agrees: Es[b]
+    [N_b, K_b], Ets[b] its transpose, M_out [B, l, l].  Every member's result is that of lowrank_fit_front on it alone.
+    Returns the context lowrank_fit_back_group needs."""
+    import ctypes
+    B = len(Es)
+    Es = [_chk(E, BF16, "E") for E in Es]
+    Ets = [_chk(Et, BF16, "Et") for Et in Ets]
+    M_out = _chk(M_out, torch.float32, "M_out")
+    shapes = [tuple(E.shape) for E in Es]
+    if any(len(sh) != 2 for sh in shapes) or any(tuple(Et.shape) != (K, N) for Et, (N, K) in zip(Ets, shapes)):
+        raise ValueError("Es must be matrices and Ets their transposes")
+    Dm = min(shapes[0])
+    if any(min(sh) != Dm for sh in shapes):
+        raise ValueError("the matrices of a group must share their short dimension")
+    l = fit_subspace(Dm, Dm, r, oversample)
+    if r > l or l >= Dm or tuple(M_out.shape) != (B, l, l):
+        raise ValueError("bad rank or Rayleigh-Ritz buffer")
+    Ns = (ctypes.c_int64 * B)(*[sh[0] for sh in shapes])
+    Ks = (ctypes.c_int64 * B)(*[sh[1] for sh in shapes])
+    state = ctypes.c_int32(-1)
+    ws = _ws(_lib.query("slim_lowrank_fit_group_workspace_bytes", ctypes.addressof(Ns), ctypes.addressof(Ks), B, l), Es[0].device)
+    pe, pet = _ptr_array(Es), _ptr_array(Ets)
+    _lib.call("slim_lowrank_fit_front_group", ctypes.addressof(pe), ctypes.addressof(pet), ctypes.addressof(Ns),
+              ctypes.addressof(Ks), B, r, l, n_iter, seed, int(flags), int(ns_steps), _p(M_out), ctypes.addressof(state),
+              _p(ws), ws.numel(), _stream())
+    return dict(ws=ws, state=state, shapes=shapes, Ns=Ns, Ks=Ks, r=r, l=l, n_iter=n_iter, keep=(Es, Ets), batch=B)
+
+
+def lowrank_fit_back_group(ctx, d, e, Q, vecs, ss=None, tail_info=None):
+    """Second half for the group of lowrank_fit_front_group: d, e [B, l], Q, vecs [B, l, l]; ss: per-member scale vectors
+    (entries may be None).  Returns one dict(U, Ut, L, S, info) per member."""
+    import ctypes
+    B, r, l, shapes = ctx["batch"], ctx["r"], ctx["l"], ctx["shapes"]
+    dev = Q.device
+    d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
+    if Q.numel() != B * l * l or vecs.numel() != B * l * l or d.numel() != B * l or e.numel() != B * l:
+        raise ValueError("eigen-solver operands do not match the fit context")
+    if tail_info is not None:
+        info1 = _chk(tail_info, torch.int32, "tail_info")
+        if info1.numel() != B:
+            raise ValueError("tail_info must hold one status word per problem")
+    else:
+        info1 = eigh_tail(d.reshape(B, l), e.reshape(B, l), Q.reshape(B, l, l), vecs.reshape(B, l, l), r)
+    ss = list(ss) if ss is not None else [None] * B
+    for s, (N, K) in zip(ss, shapes):
+        if s is not None and _chk(s, torch.float32, "s").numel() != K:
+            raise ValueError("s must hold one scale per input channel")
+    U = [torch.empty(N, r, dtype=BF16, device=dev) for N, K in shapes]
+    Ut = [torch.empty(r, N, dtype=BF16, device=dev) for N, K in shapes]
+    L = [torch.empty(K, r, dtype=BF16, device=dev) for N, K in shapes]
+    S = torch.empty(B, r, dtype=torch.float32, device=dev)
+    info = torch.empty(B, 64, dtype=torch.int32, device=dev)
+    ws = ctx["ws"]
+    ps, pu, put, pl = _ptr_array(ss), _ptr_array(U), _ptr_array(Ut), _ptr_array(L)
+    _lib.call("slim_lowrank_fit_back_group", ctypes.addressof(ctx["Ns"]), ctypes.addressof(ctx["Ks"]), B, r, l,
+              ctypes.addressof(ctx["state"]), _p(vecs), _p(d), _p(info1), ctypes.addressof(ps), ctypes.addressof(pu),
+              ctypes.addressof(put), ctypes.addressof(pl), _p(S), _p(info), _p(ws), ws.numel(), _stream())
+    return [dict(U=U[b], Ut=Ut[b], L=L[b], S=S[b], info=info[b], l=l) for b in range(B)]
+
+
 # ---- the Gram-side fit in pieces (layers sharded over several GPUs) ---------------------------------------
 def gramfit_iterate(C16, l, n_iter, seed=0, flags=0, cond_e=0):
     """Subspace iteration on the symmetric bf16 matrix C16 [Dm, Dm] -> (P [Dm, l], Pt [l, Dm], info int32 [64])."""

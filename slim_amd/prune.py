@@ -37,10 +37,14 @@ STATS_CALLBACK = None
 COMPRESS_STREAMS = int(os.environ.get("SLIM_COMPRESS_STREAMS", "7"))
 # the eigenproblems of a block's fits share one batched tridiagonalisation chain (SLIM_SHARED_EIGH=0: every fit solves its own)
 SHARED_EIGH = os.environ.get("SLIM_SHARED_EIGH", "1") == "1"
-# with the shared eigen-solver: linears of a block with the same shape and input statistics (q/k/v, gate/up) run their fits
-# as one lockstep chain (SLIM_GROUP_FITS=0: one chain per linear)
+# with the shared eigen-solver: linears of a block with the same short dimension, rank and Newton-Schulz depth (all seven of a
+# LLaMA-2-7B block) run their fits as lockstep chains (SLIM_GROUP_FITS=0: one chain per linear)
 GROUP_FITS = os.environ.get("SLIM_GROUP_FITS", "1") == "1"
-GROUP_MAX = int(os.environ.get("SLIM_GROUP_MAX", "0"))
+# at most this many members per chain (0: no limit).  Measured on a LLaMA-2-7B-shaped block (seven linears with one short
+# dimension): two chains of 4 + 3 members 22.4 ms, three of 3 + 3 + 1 22.4 ms, one chain of 7 25.0 ms (nothing overlaps its
+# eigen-solver launches), four chains 29 ms; letting the second chain's front wait for the first one's (so that it runs
+# behind the first chain's eigen-solver) 25.7 ms: the fronts, chains of small launches themselves, gain more side by side
+GROUP_MAX = int(os.environ.get("SLIM_GROUP_MAX", "4"))
 # with lockstep groups: every group runs its own eigen-solver chain right after its front instead of all groups meeting
 # in one batched chain (SLIM_PIPELINE_GROUPS=0 restores that; measured 23.6 against 24.3 ms per block)
 PIPELINE_GROUPS = os.environ.get("SLIM_PIPELINE_GROUPS", "1") == "1"
@@ -53,8 +57,8 @@ SHARD_LINEARS = os.environ.get("SLIM_SHARD_LINEARS", "1") == "1"
 _side_streams = {}
 
 
-def _streams_for(dev, n):
-    key = (dev.index, n)
+def _streams_for(dev, n, pool=None):
+    key = (dev.index, n, pool)
     if key not in _side_streams:
         _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
     return _side_streams[key]
@@ -96,14 +100,15 @@ STREAM_THREADS = os.environ.get("SLIM_STREAM_THREADS", "1") != "0" and not PROFI
 LAST_STREAM_TRACE = []
 
 
-def run_on_streams(jobs, dev, n_streams=None, stream_ids=None):
+def run_on_streams(jobs, dev, n_streams=None, stream_ids=None, pool=None):
     """Run independent GPU jobs (callables that only enqueue work and return the tensors they produced) on side
     streams that start after the current stream's pending work; the current stream then waits for all of them.
 
     Each side stream is fed by its own host thread.  One compression job issues thousands of small launches
     (the eigen-solver alone is a storm of tiny kernels), so a single host thread, not the GPU, is the limit;
     the library calls release the GIL, which lets the threads enqueue concurrently.  Jobs are assigned
-    round-robin in order, so the stream (and the result) of every job is deterministic."""
+    round-robin in order, so the stream (and the result) of every job is deterministic.  pool: names a set of side
+    streams of its own (a job that itself fans work out must not share streams with the chains running beside it)."""
     n = COMPRESS_STREAMS if n_streams is None else n_streams
     main = torch.cuda.current_stream(dev)
     if n <= 1 or len(jobs) <= 1:
@@ -111,11 +116,11 @@ def run_on_streams(jobs, dev, n_streams=None, stream_ids=None):
             job()
         return
     if stream_ids and len(jobs) <= len(stream_ids) and max(stream_ids) < n:
-        pool = _streams_for(dev, n)            # a chosen subset of the full set of side streams
-        streams = [pool[i] for i in stream_ids[:len(jobs)]]
+        full = _streams_for(dev, n, pool)      # a chosen subset of the full set of side streams
+        streams = [full[i] for i in stream_ids[:len(jobs)]]
     else:
-        streams = _streams_for(dev, min(n, len(jobs)))
-    trace = STREAM_TRACE
+        streams = _streams_for(dev, min(n, len(jobs)), pool)
+    trace = STREAM_TRACE and pool is None      # the outermost call only: nested fan-outs would overwrite its record
     ev = torch.cuda.Event(enable_timing=trace)
     ev.record(main)
     errors = []
@@ -161,6 +166,24 @@ def run_on_streams(jobs, dev, n_streams=None, stream_ids=None):
         LAST_STREAM_TRACE[:] = [dict(job=idx, stream=si, host_start_ms=h0 * 1e3, host_end_ms=h1 * 1e3,
                                      gpu_start_ms=ev.elapsed_time(e0), gpu_end_ms=ev.elapsed_time(e1))
                                 for idx, si, h0, h1, e0, e1 in sorted(records)]
+
+
+# SLIM_PHASE_TRACE=1 (debugging aid): every chain of compress_linears waits for the GPU after each of its phases and appends
+# (chain, phase, milliseconds since the chain started) to LAST_PHASE_TRACE; the waits serialise host and GPU, so the run
+# is slower than an untraced one
+PHASE_TRACE = os.environ.get("SLIM_PHASE_TRACE", "0") == "1"
+LAST_PHASE_TRACE = []
+
+
+def _phase_marker(chain):
+    if not PHASE_TRACE:
+        return lambda name: None
+    t0 = time.perf_counter()
+
+    def mark(name):
+        torch.cuda.current_stream().synchronize()
+        LAST_PHASE_TRACE.append((chain, name, (time.perf_counter() - t0) * 1e3))
+    return mark
 
 
 def _device():
@@ -248,22 +271,26 @@ def _run_block(layer, src, dst, kwargs, batch):
 COND_WORD = 63        # SLIM_FIT_INFO_COND_WORD of the last 64-word status block of a fit
 
 
-def check_fit_status(items):
+def check_fit_status(items, levels=None):
     """Raise if the low-rank fit of any of these linears reported a failure (a status word of its eigen-solver or of an
     orthonormalisation is non-zero): such a fit leaves arbitrary adapters and a residual weight quantised against them.
     Returns {index in items: level} for the fits that ask to be repeated with orthonormalisations sized for a wider
-    spread of singular values (their last status word).  One host synchronisation for the whole block."""
+    spread of singular values (their last status word).  levels (a dict, optional) receives {index in items: the spread
+    the fit measured} (status word SLIM_FIT_INFO_LEVEL_WORD; fits that report none are left out).  One host
+    synchronisation for the whole block."""
     named = [(i, name, lin.lora_fit_info) for i, (name, lin, _) in enumerate(items)
              if getattr(lin, "lora_fit_info", None) is not None]
     if not named:
         return {}
-    flags = torch.stack([torch.stack([info[:-1].ne(0).any().to(torch.int32), info[-1].to(torch.int32)])
+    flags = torch.stack([torch.stack([info[:-2].ne(0).any().to(torch.int32), info[-1].to(torch.int32), info[-2].to(torch.int32)])
                          for _, _, info in named]).cpu().tolist()
-    failed = [(name, info[:-1].cpu().tolist()) for (_, name, info), f in zip(named, flags) if f[0]]
+    failed = [(name, info[:-2].cpu().tolist()) for (_, name, info), f in zip(named, flags) if f[0]]
     if failed:
         from ._lib import SlimHipError, ERR_SOLVER
         raise SlimHipError("low-rank fit", ERR_SOLVER, "; ".join(
             f"{name}: status words {[w for w in words if w][:8]}" for name, words in failed))
+    if levels is not None:
+        levels.update({i: int(f[2]) for (i, _, _), f in zip(named, flags) if f[2] > 0})
     return {i: int(f[1]) for (i, _, _), f in zip(named, flags) if f[1] > 0}
 
 
@@ -277,28 +304,41 @@ def _reset_linear(lin, weight):
         del lin._forward_hooks[key]
 
 
-def compress_linears(items, dev, *args, **kwargs):
+def compress_linears(items, dev, *args, level_hints=None, **kwargs):
     """compress_linears_unchecked, then the status words of the fits (one host synchronisation per block): failures
     raise; fits whose orthonormalisations turned out to be sized for too narrow a spectrum are repeated once with the
-    level they report."""
+    level they report.
+    level_hints (a dict the caller keeps from block to block, optional): the fits of this block are sized from what the
+    same linears (same name and shape) measured in the last block that used the dict, and leave their own measurements in
+    it.  Neighbouring decoder blocks have similar error spectra, and a measured spread is tighter than the estimate from
+    the saliency scales, which saves Newton-Schulz steps; a fit whose hint turns out too low is repeated without it."""
     from . import lora as _lora
     originals = [lin.weight.data for _, lin, _ in items]
     masks = [getattr(lin.weight, "mask", None) for _, lin, _ in items]
+    keys = [(name, tuple(lin.weight.shape)) for name, lin, _ in items]
+    for key, (_, _, wrapped) in zip(keys, items):
+        wrapped.fit_level_hint = level_hints.get(key, 0) if level_hints is not None else 0
     compress_linears_unchecked(items, dev, *args, **kwargs)
-    again = check_fit_status(items)
-    if not again:
-        return
-    for i in again:
-        _reset_linear(items[i][1], originals[i])
-        if masks[i] is not None:
-            items[i][1].weight.mask = masks[i]
-    floor = _lora.FIT_COND_FLOOR
-    _lora.FIT_COND_FLOOR = max(again.values())
-    try:
-        compress_linears_unchecked([items[i] for i in sorted(again)], dev, *args, **kwargs)
-    finally:
-        _lora.FIT_COND_FLOOR = floor
-    check_fit_status([items[i] for i in sorted(again)])       # failures still raise; a second request is not followed
+    found = {}
+    again = check_fit_status(items, found)
+    if again:
+        for i in again:
+            _reset_linear(items[i][1], originals[i])
+            if masks[i] is not None:
+                items[i][1].weight.mask = masks[i]
+        floor = _lora.FIT_COND_FLOOR
+        _lora.FIT_COND_FLOOR = max(again.values())
+        order = sorted(again)
+        try:
+            compress_linears_unchecked([items[i] for i in order], dev, *args, **kwargs)
+        finally:
+            _lora.FIT_COND_FLOOR = floor
+        refound = {}
+        check_fit_status([items[i] for i in order], refound)      # failures still raise; a second request is not followed
+        found.update({order[j]: w for j, w in refound.items()})
+    if level_hints is not None:
+        for i, word in found.items():
+            level_hints[keys[i]] = _lora.level_hint_from_status(word)
 
 
 def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
@@ -308,13 +348,13 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
     """Compress the linears of one block after their statistics pass (the body of the per-linear loop of
     prune.py:256-357).  items: list of (name, nn.Linear, WrappedGPT) with block_stats() already applied.
 
-    With adapters the work runs in phases, each spread over the side streams: (1) per group of linears with the same
-    shape and input statistics (q/k/v, gate/up): mask, first scale search, error matrix and the low-rank fit up to its
-    l x l Rayleigh-Ritz matrix, as one lockstep chain; (2) ONE batched eigen-solver chain per eigenproblem size for the
-    whole block; (3) per group: the factors; (4) per linear: residual weight, second scale search, re-quantisation,
-    adapter attributes and hook.
+    With adapters the linears whose fits have the same short dimension, rank and Newton-Schulz depth form chains of at most
+    GROUP_MAX members, every chain on a side stream of its own: per member mask, first scale search, error matrix, outlier
+    columns split off; the low-rank fit of all members in lockstep up to their l x l Rayleigh-Ritz matrices (the subspace
+    iteration as one batched launch sequence); one batched eigen-solver chain; the factors; per member residual weight,
+    second scale search, re-quantisation, adapter attributes and hook.
     shard=True (several ranks, every rank passing the same items): the row-block partition of sharded.py instead."""
-    from .lora import add_lora_prepare, add_lora_fit, add_lora_finish
+    from .lora import add_lora_prepare, add_lora_fit, add_lora_finish, add_lora_deflate
     if shard:
         # every rank holds a block of every linear (the caller has checked sharded.supported on these items)
         from . import sharded
@@ -395,8 +435,9 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
         from . import lora as _lora
         plans = [_lora.planned_fit_group(lin, lora_rank, tile, slim_lora, wrapped) for _, lin, wrapped in items]
         if all(p is not None for p in plans):
-            # linears with equal plans (q/k/v and gate/up of a LLaMA block: same shape, same input statistics) run as ONE
-            # lockstep chain whose launches carry the whole group; the others are chains of their own
+            # linears with equal plans (all seven of a LLaMA block: same short dimension, rank and Newton-Schulz depth) run
+            # as ONE lockstep chain whose subspace iteration is a single batched launch sequence; SLIM_GROUP_MAX caps the
+            # members of a chain, and several chains overlap on their own streams
             fit_groups = {}
             seen = {}
             for idx, (key, l) in enumerate(plans):
@@ -405,91 +446,90 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                 part = n_seen // GROUP_MAX if GROUP_MAX > 0 else 0          # at most GROUP_MAX members per chain
                 fit_groups.setdefault((key, l, part) if GROUP_FITS else (key, l, idx), []).append(idx)
             fit_groups = list(fit_groups.items())
-            count, where, gbuf = {}, [], []
+            count, where = {}, []
             for gkey, members in fit_groups:
                 l = gkey[1]
                 where.append((l, count.get(l, 0)))
                 count[l] = count.get(l, 0) + len(members)
-                (N, K), t = gkey[0][0], gkey[0][3]
-                gbuf.append((torch.empty(len(members), N, K, dtype=torch.bfloat16, device=dev),
-                             torch.empty(len(members), K, N, dtype=torch.bfloat16, device=dev), t)
-                            if len(members) > 1 else None)
             Mb = {l: torch.empty(n, l, l, dtype=torch.float32, device=dev) for l, n in count.items()}
             split = len(items) < 3          # fewer fits than that do not fill the chip by themselves
 
-            def prepare_into(idx, E_out, Et_out):
-                name, lin, wrapped = items[idx]
-                if describe:
-                    describe(name)
-                ctxs[idx] = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
-                                             separate_lora, tile, quantize_first, scale_important_weights, E_out, Et_out)
-
-            def prepare_member(g, b):
-                idx = fit_groups[g][1][b]
-                if gbuf[g] is None or gbuf[g][2] != 0:
-                    prepare_into(idx, None, None)
-                else:                                   # without deflation the error matrices are the strided operands
-                    prepare_into(idx, gbuf[g][0][b], gbuf[g][1][b])
-                return ctxs[idx].tensors()
-
-            def front(g):
+            def fit_front(g):
                 members = fit_groups[g][1]
                 l, b0 = where[g]
-                if gbuf[g] is None:
-                    prepare_member(g, 0)
+                if len(members) == 1:
                     _lora.add_lora_fit_front(ctxs[members[0]], Mb[l][b0], sketch_split=split)
                 else:
-                    Eg, Etg, t = gbuf[g]
-                    for b in range(len(members)):
-                        prepare_member(g, b)
-                    _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], Eg, Etg,
-                                                   sketch_split=split)
-                return [x for i in members for x in ctxs[i].tensors()] + ([gbuf[g][0], gbuf[g][1]] if gbuf[g] else [])
+                    _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], sketch_split=split)
 
-            def back(g, tri):
+            def fit_back(g, d, e, Q, Mg, tail):
                 members = fit_groups[g][1]
-                l, b0 = where[g]
-                d, e, Q = tri[l]
-                if gbuf[g] is None:
-                    _lora.add_lora_fit_back(ctxs[members[0]], d[b0], e[b0], Q[b0], Mb[l][b0], tails[l][b0:b0 + 1])
+                if len(members) == 1:
+                    _lora.add_lora_fit_back(ctxs[members[0]], d[0], e[0], Q[0], Mg[0], tail[0:1])
                 else:
-                    sl = slice(b0, b0 + len(members))
-                    _lora.add_lora_fit_back_group([ctxs[i] for i in members], d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
-                return [x for i in members for x in ctxs[i].tensors()]
+                    _lora.add_lora_fit_back_group([ctxs[i] for i in members], d, e, Q, Mg, tail)
+
+            def fit_rank(g):
+                ctx = ctxs[fit_groups[g][1][0]].pending["ctx"]
+                return ctx["r"]
 
             ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
+            def prepare_and_deflate(idx):
+                prepare(idx)
+                add_lora_deflate(ctxs[idx])
+                return ctxs[idx].tensors()
+
             if PIPELINE_GROUPS and len(fit_groups) <= 4:
-                # every group runs its whole chain -- front, its own batched eigen-solver chain, factors, finishes -- on its
-                # stream without waiting for the others: the latency-bound eigen-solver launches of a group that is done
-                # early overlap the GEMMs of the groups still in their fronts
+                # every chain runs whole -- its members' first phases, the lockstep front, its own batched eigen-solver chain, the
+                # factors, its members' last phases -- on its stream without waiting for the others: the latency-bound
+                # eigen-solver launches of a chain overlap the GEMMs of the others.  (More host threads than chains do not
+                # pay: spreading the members' first phases over seven threads was slower than running them in the chain.)
                 def whole_group(g):
                     members = fit_groups[g][1]
                     l, b0 = where[g]
-                    out = front(g)
-                    sl = slice(b0, b0 + len(members))
-                    Mg = Mb[l][sl]
+                    mark = _phase_marker(g)
+                    for i in members:
+                        prepare_and_deflate(i)
+                    mark("prepare")
+                    fit_front(g)
+                    mark("front")
+                    Mg = Mb[l][b0:b0 + len(members)]
                     d, e, Q = ops.tridiagonalize_batched(Mg)
-                    r_fit = ctxs[members[0]].pending["ctx"]["r"]
-                    tail = ops.eigh_tail(d, e, Q, Mg, r_fit)
-                    if gbuf[g] is None:
-                        _lora.add_lora_fit_back(ctxs[members[0]], d[0], e[0], Q[0], Mg[0], tail[0:1])
-                    else:
-                        _lora.add_lora_fit_back_group([ctxs[i] for i in members], d, e, Q, Mg, tail)
+                    mark("tridiagonalize")
+                    tail = ops.eigh_tail(d, e, Q, Mg, fit_rank(g))
+                    mark("eigh_tail")
+                    fit_back(g, d, e, Q, Mg, tail)
+                    mark("back")
+                    out = [d, e, Q, tail]
                     for i in members:
                         out += finish(i)
-                    return out + [d, e, Q, tail]
+                    mark("finish")
+                    return out
                 run_on_streams([lambda g=g: whole_group(g) for g in range(len(fit_groups))], dev, n_streams, ids)
                 return
+
+            def front(g):
+                for i in fit_groups[g][1]:
+                    prepare(i)
+                fit_front(g)
+                return [x for i in fit_groups[g][1] for x in ctxs[i].tensors()]
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             # the eigenproblems of the block, size by size: one tridiagonalisation chain and three launches for the
             # tridiagonal stage, each carrying every problem of that size
             tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
             top = {}
             for g in range(len(fit_groups)):
-                r_fit = ctxs[fit_groups[g][1][0]].pending["ctx"]["r"]
-                top[where[g][0]] = max(top.get(where[g][0], 0), r_fit)
+                top[where[g][0]] = max(top.get(where[g][0], 0), fit_rank(g))
             tails = {l: ops.eigh_tail(tri[l][0], tri[l][1], tri[l][2], Mb[l], top[l]) for l in sorted(Mb)}
-            run_on_streams([lambda g=g: back(g, tri) for g in range(len(fit_groups))], dev, n_streams, ids)
+
+            def back(g):
+                members = fit_groups[g][1]
+                l, b0 = where[g]
+                sl = slice(b0, b0 + len(members))
+                d, e, Q = tri[l]
+                fit_back(g, d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
+                return [x for i in members for x in ctxs[i].tensors()]
+            run_on_streams([lambda g=g: back(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
             return
     # a single linear, pruned or merged adapters, or an eigenproblem the shared solver does not take: the three phases of a
@@ -566,6 +606,7 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                               block_dim=weight_tile_size) if quantize_weight else None
     layers = get_layers_list(model)
     progress_bar = tqdm.tqdm(range(len(layers)))
+    level_hints = {}        # what the fits of a block measured, for the same linears of the next block (compress_linears)
     for i in progress_bar:
         progress_bar.set_description(f"Layer {i} - Gathering data")
         layer = layers[i].to(dev)
@@ -613,7 +654,8 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
             compress_linears(everything, dev, prune_n, prune_m, shard=True, **opts)
         else:
             owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)
-            compress_linears([it for j, it in enumerate(everything) if owner[j] == rank], dev, prune_n, prune_m, **opts)
+            compress_linears([it for j, it in enumerate(everything) if owner[j] == rank], dev, prune_n, prune_m,
+                             level_hints=level_hints, **opts)
             if world > 1:
                 _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
                                 quantizer is not None and not tiled_weight_quantization, separate_lora,

@@ -216,7 +216,7 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         for b, i in enumerate(idxs):
             jobs[i].M = Mb[b].contiguous()
             jobs[i].evals = d[b].contiguous()
-            jobs[i].info[62] = tail[b]
+            jobs[i].info[61] = tail[b]
     for j in jobs:
         if j.owner != rank:
             j.evals = torch.empty(j.l, dtype=torch.float32, device=dev)
@@ -256,7 +256,7 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         lin.lora_left = torch.nn.Parameter(L[:, :j.rank_].contiguous() * sq)
         lin.lora_right = torch.nn.Parameter(ops.transpose(U)[:j.rank_].contiguous() * sq)
         lin.register_forward_hook(add_lora_hook)
-        bad = j.info[:-1].ne(0).any()
+        bad = j.info[:-2].ne(0).any()
         if j.info_o is not None:
             bad = bad | j.info_o.ne(0).any()
         status[idx, 0] = bad.to(torch.int32)

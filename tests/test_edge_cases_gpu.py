@@ -118,7 +118,7 @@ def test_stream_feeding_modes_agree(ops):
         P.STREAM_THREADS, P.STREAM_TRACE = threads, trace
         try:
             items = []
-            for i, (n, k) in enumerate([(128, 256), (256, 256), (256, 128)]):     # three shapes: three chains, one per stream
+            for i, (n, k) in enumerate([(128, 256), (256, 256), (512, 384)]):     # three short dimensions: three chains, one per stream
                 lin = torch.nn.Linear(k, n, bias=False, device=DEV, dtype=torch.bfloat16)
                 lin.weight.data = synth_weight(n, k, 40 + i).to(DEV)
                 wr = WrappedGPT(lin)

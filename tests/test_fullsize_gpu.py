@@ -46,13 +46,24 @@ def _error_matrix(ops, N, K, seed):
     return E, sr
 
 
-def _excess(E, U, L, rank):
+def _excess(E, U, L, rank, sv=None):
     """||E - U L^T||_F over the optimum sqrt(sum_{i > r} sigma_i^2), minus one."""
     Ef = E.float()
-    sv = torch.linalg.svdvals(Ef)
+    sv = torch.linalg.svdvals(Ef) if sv is None else sv
     opt = float(torch.sqrt((sv[rank:].double() ** 2).sum()))
     err = float(torch.norm(Ef - U.float() @ L.float().t()))
     return err / opt - 1, float(sv[0] / sv[rank - 1]), float(sv[rank - 1] / sv[min(rank + 127, len(sv) - 1)])
+
+
+def _hinted_refit(ops, E, rank, outl, spread, info):
+    """The fit again, sized as the driver sizes the same linear of the next block: from the spread this fit measured
+    (status word 62).  Returns (U, L, hint) -- the second fit must not ask to be repeated."""
+    from slim_amd.lora import fit_error_matrix, level_hint_from_status, fit_ns_steps
+    hint = level_hint_from_status(int(info[-2]))
+    assert hint >= 2
+    U, Ut, L, info2 = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread, hint=hint)
+    assert int(info2[:-2].abs().sum()) == 0 and int(info2[-1]) == 0, info2[-2:]
+    return U, L, fit_ns_steps(spread, hint)
 
 
 # N, K, rank: the distinct linears of LLaMA-2-7B (4096 x 4096, 11008 x 4096, 4096 x 11008; r = 512), the largest of
@@ -70,11 +81,17 @@ def test_fit_within_1e3_of_truncated_svd_full_size(ops, N, K, rank):
     E, sr = _error_matrix(ops, N, K, 100 + N % 97 + K % 89)
     outl, spread = outlier_columns(sr)
     U, Ut, L, info = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread)
-    assert int(info[:-1].abs().sum()) == 0
-    excess, cond, flat = _excess(E, U[:, :rank], L[:, :rank], rank)
+    assert int(info[:-2].abs().sum()) == 0
+    sv = torch.linalg.svdvals(E.float())
+    excess, cond, flat = _excess(E, U[:, :rank], L[:, :rank], rank, sv)
+    # and sized from its own measured spread, as the same linear of the next decoder block would be
+    U2, L2, levels = _hinted_refit(ops, E, rank, outl, spread, info)
+    excess2, _, _ = _excess(E, U2[:, :rank], L2[:, :rank], rank, sv)
     print(f"{N}x{K} r={rank}: sigma_1/sigma_r {cond:.1f}, sigma_r/sigma_(r+128) {flat:.4f}, deflated "
-          f"{0 if outl is None else outl[1]}, excess over the truncated SVD {excess:+.2e}")
+          f"{0 if outl is None else outl[1]}, excess over the truncated SVD {excess:+.2e}; sized from the measured spread "
+          f"(levels {levels & 255} -> {levels >> 8}): {excess2:+.2e}")
     assert excess <= 1e-3, excess
+    assert excess2 <= 1e-3, excess2
 
 
 def test_full_size_check_detects_too_few_iterations(ops):
@@ -147,7 +164,7 @@ def test_fit_within_1e3_at_llama3_70b_mlp_shapes(ops, N, K, rank):
     E, sr = _error_matrix(ops, N, K, 300 + N % 97)
     outl, spread = outlier_columns(sr, rank=rank)
     U, Ut, L, info = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread)
-    assert int(info[:-1].abs().sum()) == 0
+    assert int(info[:-2].abs().sum()) == 0
     opt, cond = _optimum_from_gram(E, rank)
     # the error in fp64 by blocks of rows (the full fp32 difference matrix would be 0.9 GB, fine, but fp64 keeps the sum exact)
     err2 = 0.0
@@ -156,6 +173,15 @@ def test_fit_within_1e3_at_llama3_70b_mlp_shapes(ops, N, K, rank):
         D = E[r0:r0 + 4096].double() - Uf[r0:r0 + 4096] @ Lf.t()
         err2 += float((D * D).sum())
     excess = err2 ** 0.5 / opt - 1
+    U2, L2, levels = _hinted_refit(ops, E, rank, outl, spread, info)
+    err2 = 0.0
+    Uf, Lf = U2[:, :rank].double(), L2[:, :rank].double()
+    for r0 in range(0, N, 4096):
+        D = E[r0:r0 + 4096].double() - Uf[r0:r0 + 4096] @ Lf.t()
+        err2 += float((D * D).sum())
+    excess2 = err2 ** 0.5 / opt - 1
     print(f"{N}x{K} r={rank}: sigma_1/sigma_r {cond:.1f}, deflated {0 if outl is None else outl[1]}, "
-          f"excess over the truncated SVD {excess:+.2e}")
+          f"excess over the truncated SVD {excess:+.2e}; sized from the measured spread (levels {levels & 255} -> "
+          f"{levels >> 8}): {excess2:+.2e}")
     assert excess <= 1e-3, excess
+    assert excess2 <= 1e-3, excess2

@@ -34,7 +34,7 @@ def test_split_fit_equals_single_call():
     for i in range(len(shapes)):
         got = ops.lowrank_fit_back(ctxs[i], d[i], e[i], Q[i], Mb[i], s=ss[i])
         torch.cuda.synchronize()
-        assert int(got["info"][..., :-1].abs().sum()) == 0
+        assert int(got["info"][..., :-2].abs().sum()) == 0
         for k in ("U", "Ut", "L"):
             assert torch.equal(got[k], refs[i][k]), (i, k)
         torch.testing.assert_close(got["S"], refs[i]["S"], rtol=0, atol=0)
@@ -64,7 +64,7 @@ def test_batched_split_fit_equals_single_call():
     d, e, Q = ops.tridiagonalize_batched(Mb)
     got = ops.lowrank_fit_back(ctx, d, e, Q, Mb, s=torch.stack(ss))
     torch.cuda.synchronize()
-    assert int(got["info"][..., :-1].abs().sum()) == 0
+    assert int(got["info"][..., :-2].abs().sum()) == 0
     for i in range(B):
         for k in ("U", "Ut", "L"):
             assert torch.equal(got[k][i], refs[i][k]), (i, k)
@@ -136,7 +136,7 @@ def test_underestimated_conditioning_is_detected_and_the_fit_repeated():
     s[torch.randperm(K, generator=g)[:200]] *= 9.0          # many channels 9x the median: below the split-off ratio
     sr = (s ** 2 * 2048).float()
 
-    def run(cond_e):
+    def run(cond_e, hints=None):
         calls = []
         lin = torch.nn.Linear(K, N, bias=False).to(torch.bfloat16).cuda()
         lin.weight.data = W.cuda()
@@ -147,10 +147,10 @@ def test_underestimated_conditioning_is_detected_and_the_fit_repeated():
         real, real_steps = P.compress_linears_unchecked, LORA.fit_ns_steps
         P.compress_linears_unchecked = lambda *a, **k: (calls.append(LORA.FIT_COND_FLOOR), real(*a, **k))[1]
         if cond_e is not None:
-            LORA.fit_ns_steps = lambda spread: max(cond_e, LORA.FIT_COND_FLOOR)
+            LORA.fit_ns_steps = lambda spread, hint=0: max(cond_e, LORA.FIT_COND_FLOOR)
         try:
             P.compress_linears([("lin", lin, wrapped)], torch.device("cuda", 0), 2, 4, quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
-                               lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=128)
+                               lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=128, level_hints=hints)
         finally:
             P.compress_linears_unchecked, LORA.fit_ns_steps = real, real_steps
         eff = lin.weight.data.float() + (lin.lora_right.data.float().t() @ lin.lora_left.data.float().t()) / float(lin.lora_rank)
@@ -163,3 +163,14 @@ def test_underestimated_conditioning_is_detected_and_the_fit_repeated():
     assert len(calls_wide) == 1 and word_wide == 0
     assert len(calls_low) == 2 and calls_low[1] >= 2           # detected, repeated with the level the fit reported
     assert err_low <= err_wide * (1 + 1e-3)
+
+    # the same through a hint that is too low (a previous block with a much narrower spectrum): detected, repeated without
+    # the hint, and the dictionary then holds what this layer measured
+    hints = {("lin", (N, K)): 2}
+    err_hint, calls_hint, _ = run(None, hints)
+    print(f"too low a hint: {err_hint:.4f} ({len(calls_hint)} passes), hint left behind {hints}")
+    assert len(calls_hint) == 2 and hints[("lin", (N, K))] > 2
+    assert err_hint <= err_wide * (1 + 1e-3)
+    # and with the hint it left behind: one pass, as good
+    err_next, calls_next, word_next = run(None, hints)
+    assert len(calls_next) == 1 and word_next == 0 and err_next <= err_wide * (1 + 1e-3)
