@@ -343,6 +343,24 @@ int64_t slim_lora_finish_workspace_bytes(int64_t N, int64_t K);
 int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t K, int r8, int rank, const void* W_bf16,
                      const uint8_t* mask, int quant_mode, int num_bits, int prescale, void* W_out_bf16, float* sf_out,
                      void* lora_left_out, void* lora_right_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* The head of add_lora with the Wanda mask before it, slim/prune.py:264-272 + slim/lora.py:139-156, for a per-tensor
+ * quantiser (or none) and quantize_first, in one call: s_out [K] = sqrt(scaler_row); mask [N, K] = prune_nm(|W| * s, prune_n,
+ * prune_m) when prune_n > 0 (else `mask` is read: a precomputed mask, prune.py:269-271); sf_out = the scale of W (quant_mode
+ * as in slim_lora_finish); E, Et = the bf16 error matrix W s' - mask0(deq(quant(W)) s') and its transpose (s' = s when
+ * scale_error != 0: the `any(scaler_row == 0)` guard of lora.py:139 is the caller's).  No counterpart in the reference for
+ * the rest: when t > 0 outlier columns of E are listed (outlier_idx, tp entries, tp a multiple of 8 and at most 64, the
+ * first t real), UO [N, tp] / UOt [tp, N] receive an orthonormal basis of those columns (columns >= t zero), Ct [K, tp] =
+ * (UO^T E)^T, E2 = E - UO Ct^T and E2t its transpose: what the randomized fit of slim_lowrank_fit* then runs on.
+ * slim_outlier_basis is the basis step alone: the columns cols[0 .. t) of E are rows of Et [K, N]; the basis is E_O D^-1 R^-1
+ * with D the column norms and R the Cholesky factor of the normalised columns' Gram matrix (double precision). */
+int64_t slim_outlier_basis_workspace_bytes(int tp);
+int slim_outlier_basis(const void* Et_bf16, int64_t N, const int32_t* cols, int t, int tp, void* UO, void* UOt, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+int64_t slim_lora_prepare_workspace_bytes(int64_t N, int64_t K, int tp);
+int slim_lora_prepare(const void* W_bf16, const float* scaler_row, int64_t N, int64_t K, int prune_n, int prune_m, uint8_t* mask,
+                      int quant_mode, int num_bits, int scale_error, float* s_out, float* sf_out, void* E_bf16, void* Et_bf16,
+                      const int32_t* outlier_idx, int t, int tp, void* UO, void* UOt, void* Ct, void* E2_bf16, void* E2t_bf16,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 /* Same subtraction from a materialised LR, optionally accumulating the |bf16| histogram of Wn. */
 int slim_residual_weight(const void* W_bf16, const void* LR_bf16, const uint8_t* mask, int64_t numel, void* Wn_bf16,
                          uint32_t* hist, void* stream);

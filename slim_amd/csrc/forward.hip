@@ -44,16 +44,25 @@ __host__ __device__ __forceinline__ int64_t packed_unit(int64_t row, int64_t k32
     return ((tn * (K >> 6) + kt) * 2 + half) * 128 + r;
 }
 
-// one thread per (row, 32-channel chunk); status bit 0: a group with more than two non-zeros,
-// bit 1: a value that is not bf16(c / sf) for an integer c in [-8, 7]
-__global__ void pack24_kernel(const bf16_t* __restrict__ W, const float* __restrict__ sf_ptr, int64_t N, int64_t K,
-                              uint8_t* __restrict__ vals, uint8_t* __restrict__ meta, int* __restrict__ status) {
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t chunks = K >> 5;
-    if (u >= N * chunks) return;
-    const int64_t row = u / chunks, k32 = u - row * chunks;
+// one thread per (row, 32-channel chunk), numbered in the order of the packed arrays: a 256-thread workgroup reads 128
+// rows x 128 contiguous bytes (whole cache lines) and writes 2 KiB of values and 1 KiB of positions contiguously.
+// status bit 0: a group with more than two non-zeros, bit 1: a value that is not bf16(c / sf) for an integer c in [-8, 7]
+__global__ __launch_bounds__(256) void pack24_kernel(const bf16_t* __restrict__ W, const float* __restrict__ sf_ptr, int64_t N,
+                                                     int64_t K, uint8_t* __restrict__ vals, uint8_t* __restrict__ meta,
+                                                     int* __restrict__ status) {
+    __shared__ bf16_t levels[16];
     const float sf = *sf_ptr;
+    if (threadIdx.x < 16) levels[threadIdx.x] = f32_to_bf16((float)((int)threadIdx.x - 8) / sf);
+    __syncthreads();
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= N * (K >> 5)) return;
+    const int64_t tk = o >> 8, ktiles = K >> 6;
+    const int64_t tn = tk / ktiles, kt = tk - tn * ktiles;
+    const int64_t row = (tn << 7) + (o & 127), k32 = 2 * kt + ((o >> 7) & 1);
     const bf16_t* w = W + row * K + k32 * 32;
+    u16x8 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = *(const u16x8*)(w + 8 * i);
     uint32_t v[2] = {0u, 0u}, m = 0u;
     int bad = 0;
 #pragma unroll
@@ -61,11 +70,11 @@ __global__ void pack24_kernel(const bf16_t* __restrict__ W, const float* __restr
         int pos[2] = {0, 1}, code[2] = {0, 0}, n = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bf16_t raw = w[g * 4 + e];
+            const bf16_t raw = x[g >> 1][(g & 1) * 4 + e];
             if ((raw & 0x7fffu) == 0) continue;
-            const float f = bf16_to_f32(raw);
-            const float c = rintf(f * sf);
-            if (!(c >= -8.f && c <= 7.f) || f32_to_bf16(c / sf) != raw) bad |= 2;
+            const float c = rintf(bf16_to_f32(raw) * sf);
+            const bool in_range = c >= -8.f && c <= 7.f;
+            if (!in_range || levels[in_range ? (int)c + 8 : 0] != raw) bad |= 2;
             if (n < 2) {
                 pos[n] = e;
                 code[n] = (int)c;
@@ -82,7 +91,6 @@ __global__ void pack24_kernel(const bf16_t* __restrict__ W, const float* __restr
         v[g >> 2] |= byte << (8 * (g & 3));
         m |= ((uint32_t)pos[0] | ((uint32_t)pos[1] << 2)) << (4 * g);
     }
-    const int64_t o = packed_unit(row, k32, K);
     *(uint2*)(vals + o * 8) = make_uint2(v[0], v[1]);
     *(uint32_t*)(meta + o * 4) = m;
     if (bad) atomicOr(status, bad);

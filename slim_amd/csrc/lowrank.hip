@@ -1043,6 +1043,184 @@ extern "C" int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t
     return SLIM_OK;
 }
 
+// ---- the head of add_lora in one call ------------------------------------------------------------------------------------
+// Outlier columns of the error matrix (input channels whose saliency scale is far above the median) are split off before
+// the randomized fit: with Q_O an orthonormal basis of those t columns, E = Q_O (Q_O^T E) + E'.  The columns are rows of
+// E^T, so everything below reads contiguous rows.  The basis comes from the Cholesky factor of the columns' normalised
+// Gram matrix (Q_O = E_O D^-1 R^-1 with D the column norms): after the normalisation the columns are close to orthogonal
+// (error columns of different channels are nearly uncorrelated), so the factorisation is well conditioned, and it is
+// carried in double precision.
+
+// G[i][j] (double, [tp][tp]) = <column c_i, column c_j> for i <= j < t; one workgroup per pair
+__global__ __launch_bounds__(256) void outlier_gram_kernel(const bf16_t* __restrict__ Et, int64_t N, const int32_t* __restrict__ cols,
+                                                           int t, int tp, double* __restrict__ G) {
+    __shared__ double red[4];
+    const int i = blockIdx.y, j = blockIdx.x;
+    if (i > j || j >= t) {
+        if (threadIdx.x == 0) G[i * tp + j] = 0.0;
+        return;
+    }
+    const bf16_t* a = Et + (int64_t)cols[i] * N;
+    const bf16_t* b = Et + (int64_t)cols[j] * N;
+    double acc = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) acc += (double)(bf16_to_f32(a[n]) * bf16_to_f32(b[n]));
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) G[i * tp + j] = red[0] + red[1] + red[2] + red[3];
+}
+
+// T [tp][tp] (fp32, upper triangular) with Q_O = E_O T: one workgroup of 64 threads, thread j owns column j.  A column whose
+// pivot vanishes (a zero column, or one inside the span of the columns before it) gets a zero column of T: the basis then
+// spans the other columns only.
+__global__ __launch_bounds__(64) void outlier_basis_kernel(const double* __restrict__ G, int t, int tp, float* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double* R = sh;                 // [t][t] Cholesky factor of the normalised Gram matrix, upper triangular, row-major
+    double* Ri = sh + t * t;        // its inverse
+    double* dn = sh + 2 * t * t;    // column norms; dead[j] behind them
+    double* dead = dn + t;
+    const int j = threadIdx.x;
+    if (j < t) {
+        dn[j] = sqrt(G[j * tp + j]);
+        dead[j] = 0.0;
+    }
+    __syncthreads();
+    if (j < t)
+        for (int i = 0; i < t; ++i) {
+            const double den = dn[i] * dn[j];
+            R[i * t + j] = (i <= j && den > 0.0) ? G[i * tp + j] / den : 0.0;
+            Ri[i * t + j] = 0.0;
+        }
+    __syncthreads();
+    // right-looking Cholesky, row k at a time: R[k][k] = sqrt(pivot), R[k][j] /= R[k][k], trailing update by thread j
+    for (int k = 0; k < t; ++k) {
+        const double piv = R[k * t + k];
+        const bool ok = piv > 1e-10;
+        __syncthreads();
+        if (j == k) {
+            R[k * t + k] = ok ? sqrt(piv) : 1.0;
+            if (!ok) dead[k] = 1.0;
+        }
+        __syncthreads();
+        if (j > k && j < t) R[k * t + j] = ok ? R[k * t + j] / R[k * t + k] : 0.0;
+        __syncthreads();
+        if (j > k && j < t) {
+            const double rkj = R[k * t + j];
+            for (int i = k + 1; i <= j; ++i) R[i * t + j] -= R[k * t + i] * rkj;
+        }
+        __syncthreads();
+    }
+    // inverse of the upper triangular factor, column j by thread j (back substitution on R Ri = I)
+    if (j < t) {
+        for (int i = j; i >= 0; --i) {
+            double v = i == j ? 1.0 : 0.0;
+            for (int k = i + 1; k <= j; ++k) v -= R[i * t + k] * Ri[k * t + j];
+            Ri[i * t + j] = v / R[i * t + i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tp * tp; e += 64) {
+        const int i = e / tp, c = e - i * tp;
+        float v = 0.f;
+        if (i <= c && c < t && dead[c] == 0.0 && dead[i] == 0.0 && dn[i] > 0.0) v = (float)(Ri[i * t + c] / dn[i]);
+        T[e] = v;
+    }
+}
+
+// UOt [tp][N] and UO [N][tp] (bf16) = the basis Q_O = E_O T and its transpose; columns >= t zero.  One thread per row n.
+__global__ __launch_bounds__(256) void outlier_q_kernel(const bf16_t* __restrict__ Et, int64_t N, const int32_t* __restrict__ cols,
+                                                        int t, int tp, const float* __restrict__ T, bf16_t* __restrict__ UO,
+                                                        bf16_t* __restrict__ UOt) {
+    extern __shared__ __attribute__((aligned(16))) float ev[];      // [t][256] this workgroup's entries of the columns, then T
+    float* Ts = ev + t * 256;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int i = 0; i < t; ++i) ev[i * 256 + threadIdx.x] = n < N ? bf16_to_f32(Et[(int64_t)cols[i] * N + n]) : 0.f;
+    for (int e = threadIdx.x; e < tp * tp; e += 256) Ts[e] = T[e];
+    __syncthreads();
+    if (n >= N) return;
+    for (int c = 0; c < tp; ++c) {
+        float q = 0.f;
+        if (c < t)
+            for (int i = 0; i <= c; ++i) q += Ts[i * tp + c] * ev[i * 256 + threadIdx.x];
+        const bf16_t h = f32_to_bf16(q);
+        UOt[(int64_t)c * N + n] = h;
+        UO[n * tp + c] = h;
+    }
+}
+
+static inline int64_t prepare_search_bins(int64_t numel) { return numel / 1000 < 512 ? 512 : (numel / 1000 > 20000 ? 20000 : numel / 1000); }
+
+extern "C" int64_t slim_outlier_basis_workspace_bytes(int tp) {
+    return tp < 0 ? -1 : al256((int64_t)tp * tp * 8) + al256((int64_t)tp * tp * 4);
+}
+
+// UO [N, tp] / UOt [tp, N] = an orthonormal basis of the columns cols[0 .. t) of E, given as rows of Et [K, N]; columns >= t zero
+extern "C" int slim_outlier_basis(const void* Et, int64_t N, const int32_t* cols, int t, int tp, void* UO, void* UOt, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(Et && cols && UO && UOt && workspace, "slim_outlier_basis: null pointer");
+    SLIM_REQUIRE(N > 0 && t > 0 && tp >= t && tp % 8 == 0 && tp <= 64, "slim_outlier_basis: bad sizes");
+    SLIM_REQUIRE(workspace_bytes >= slim_outlier_basis_workspace_bytes(tp), "slim_outlier_basis: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* G = (double*)workspace;
+    float* T = (float*)((char*)workspace + al256((int64_t)tp * tp * 8));
+    outlier_gram_kernel<<<dim3((unsigned)tp, (unsigned)tp), 256, 0, st>>>((const bf16_t*)Et, N, cols, t, tp, G);
+    SLIM_LAUNCH_CHECK();
+    outlier_basis_kernel<<<1, 64, (size_t)(2 * t * t + 2 * t) * sizeof(double), st>>>(G, t, tp, T);
+    SLIM_LAUNCH_CHECK();
+    const size_t q_lds = ((size_t)t * 256 + (size_t)tp * tp) * sizeof(float);
+    SLIM_HIP(slim_allow_dynamic_lds((const void*)outlier_q_kernel, (int)q_lds));
+    outlier_q_kernel<<<(unsigned)ceil_div64(N, 256), 256, q_lds, st>>>((const bf16_t*)Et, N, cols, t, tp, T, (bf16_t*)UO, (bf16_t*)UOt);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+extern "C" int64_t slim_lora_prepare_workspace_bytes(int64_t N, int64_t K, int tp) {
+    if (N <= 0 || K <= 0 || tp < 0) return -1;
+    return al256(32768 * 4) + al256(slim_quant_search_workspace_bytes((int)prepare_search_bins(N * K))) + 256 +
+           slim_outlier_basis_workspace_bytes(tp);
+}
+
+// slim/prune.py:264-272 + slim/lora.py:139-156 for a per-tensor quantiser (or none) with quantize_first, in one call:
+//   s = sqrt(scaler_row);  mask = prune_nm(|W| * s, prune_n, prune_m) when prune_n > 0 (else `mask` is an input);
+//   sf = scale of W (quant_mode 1: SLiM-Quant search; 2: abs-max; 0: no quantiser);
+//   E = W * s' - mask0(deq(quant(W, sf)) * s') in bf16 and its transpose, s' = s when scale_error != 0, else 1;
+// and, when t > 0 outlier columns are listed (outlier_idx, padded to tp entries, tp a multiple of 8): UO [N, tp], UOt [tp, N]
+// = an orthonormal basis of those columns of E (columns >= t zero), Ct [K, tp] = (UO^T E)^T, E2 = E - UO Ct^T and E2t.
+extern "C" int slim_lora_prepare(const void* W, const float* scaler_row, int64_t N, int64_t K, int prune_n, int prune_m, uint8_t* mask,
+                                 int quant_mode, int num_bits, int scale_error, float* s_out, float* sf_out, void* E, void* Et,
+                                 const int32_t* outlier_idx, int t, int tp, void* UO, void* UOt, void* Ct, void* E2, void* E2t,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(W && scaler_row && mask && s_out && E && Et && workspace, "slim_lora_prepare: null pointer");
+    SLIM_REQUIRE(N > 0 && K > 0 && N < (1 << 30) && K < (1 << 30) && N % 8 == 0 && K % 8 == 0, "slim_lora_prepare: bad sizes");
+    SLIM_REQUIRE(quant_mode >= 0 && quant_mode <= 2 && (quant_mode == 0 || sf_out), "slim_lora_prepare: bad quantiser mode");
+    SLIM_REQUIRE(t >= 0 && tp >= t && tp % 8 == 0 && tp <= 64, "slim_lora_prepare: bad outlier counts");
+    SLIM_REQUIRE(t == 0 || (outlier_idx && UO && UOt && Ct && E2 && E2t), "slim_lora_prepare: null pointer (outlier outputs)");
+    SLIM_REQUIRE(workspace_bytes >= slim_lora_prepare_workspace_bytes(N, K, tp), "slim_lora_prepare: workspace too small");
+    const int64_t numel = N * K;
+    CHK(slim_sqrt_f32(scaler_row, s_out, K, stream));
+    if (prune_n > 0) CHK(slim_mask_nm(W, s_out, N, K, prune_n, prune_m, mask, stream));
+    uint32_t* hist = (uint32_t*)workspace;
+    char* search_ws = (char*)workspace + al256(32768 * 4);
+    const int64_t bins = prepare_search_bins(numel);
+    const int64_t search_bytes = al256(slim_quant_search_workspace_bytes((int)bins));
+    float* alpha = (float*)(search_ws + search_bytes);
+    char* basis_ws = search_ws + search_bytes + 256;
+    if (quant_mode) {
+        CHK(slim_hist_abs_bf16(W, numel, hist, 0, stream));
+        if (quant_mode == 1) CHK(slim_quant_search(hist, (int)bins, num_bits, alpha, nullptr, sf_out, search_ws, search_bytes, stream));
+        else CHK(slim_absmax_scale(hist, num_bits, alpha, sf_out, stream));
+    }
+    CHK(slim_error_matrix(W, mask, scale_error ? s_out : nullptr, quant_mode ? sf_out : nullptr, num_bits, N, K, nullptr, E, stream));
+    CHK(slim_transpose_bf16(E, N, K, Et, stream));
+    if (t == 0) return SLIM_OK;
+    CHK(slim_outlier_basis(Et, N, outlier_idx, t, tp, UO, UOt, basis_ws, slim_outlier_basis_workspace_bytes(tp), stream));
+    // Ct [K, tp] = (UOt Et^T)^T: the product's transposed output only
+    CHK(slim_gemm_nt_bf16(UOt, N, Et, N, tp, (int)K, (int)N, 1.f, 0.f, nullptr, 0, nullptr, 0, Ct, tp, stream));
+    CHK(slim_lowrank_residual(UO, Ct, (int)N, (int)K, tp, E, nullptr, E2, nullptr, stream));
+    CHK(slim_transpose_bf16(E2, N, K, E2t, stream));
+    return SLIM_OK;
+}
+
 // ---- the pieces of the Gram-side fit as separate calls -----------------------------------------------------------------
 // For a layer sharded over several GPUs along its long dimension: every GPU forms the Gram matrix of its shard of E
 // (slim_gemm_nt_bf16 with fp32 output), the sum over the shards goes to one GPU, which runs the subspace iteration

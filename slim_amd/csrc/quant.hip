@@ -111,19 +111,30 @@ __global__ __launch_bounds__(1024) void rebin_kernel(const uint32_t* __restrict_
     }
     for (int i = threadIdx.x; i < bins; i += 1024) cnt[i] = 0;
     __syncthreads();
+    // every thread's 32 pattern counts come from memory in one batch of independent loads and stay in registers for both
+    // passes: the kernel is a single workgroup, so each dependent trip to memory would be paid in full
+    uint32_t cnts[HIST_BINS / 1024];
+#pragma unroll
+    for (int u = 0; u < HIST_BINS / 1024; ++u) cnts[u] = hist[threadIdx.x + 1024 * u];
     int lo_p = HIST_BINS, hi_p = -1;
     unsigned long long tot = 0;
-    for (int p = threadIdx.x; p < HIST_BINS; p += 1024) {
-        const uint32_t c = hist[p];
-        if (c) {
+#pragma unroll
+    for (int u = 0; u < HIST_BINS / 1024; ++u) {
+        const int p = threadIdx.x + 1024 * u;
+        if (cnts[u]) {
             lo_p = min(lo_p, p);
             hi_p = max(hi_p, p);
-            tot += c;
+            tot += cnts[u];
         }
     }
-    atomicMin(&s_lo, lo_p);
-    atomicMax(&s_hi, hi_p);
-    atomicAdd(&s_total, tot);
+    lo_p = wave_min_i32(lo_p);
+    hi_p = wave_max_i32(hi_p);
+    tot = wave_sum_u64(tot);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_lo, lo_p);
+        atomicMax(&s_hi, hi_p);
+        atomicAdd(&s_total, tot);
+    }
     __syncthreads();
     float lo = bf16_to_f32((bf16_t)s_lo), hi = bf16_to_f32((bf16_t)s_hi);
     if (s_lo == s_hi) {  // constant |W|: the reference widens the range by half a unit each side
@@ -131,10 +142,11 @@ __global__ __launch_bounds__(1024) void rebin_kernel(const uint32_t* __restrict_
         hi += 0.5f;
     }
     const float step = (hi - lo) / (float)bins;
-    for (int p = threadIdx.x; p < HIST_BINS; p += 1024) {
-        const uint32_t c = hist[p];
+#pragma unroll
+    for (int u = 0; u < HIST_BINS / 1024; ++u) {
+        const uint32_t c = cnts[u];
         if (!c) continue;
-        const float v = bf16_to_f32((bf16_t)p);
+        const float v = bf16_to_f32((bf16_t)(threadIdx.x + 1024 * u));
         int pos = (int)((v - lo) / (hi - lo) * (float)bins);
         pos = max(0, min(pos, bins - 1));
         while (pos > 0 && v < edge_at(pos, bins, lo, hi, step)) --pos;
@@ -170,12 +182,13 @@ __device__ __forceinline__ float floor_div_f32(float a, float b) {
 
 // loss of one candidate index, reduced over the workgroup (256 threads); element-wise terms
 // are formed with the reference's fp32 operations, the sum is carried in fp64.
+template <int NT>
 __device__ float candidate_loss(const SearchWs& ws, int bins, int index, int q, double* red) {
     const float alpha = ws.val[index];
     const float dx = ws.val[1] - ws.val[0];
     const float step = alpha / (float)(1 << q);
     double sq = 0.0, sc = 0.0;
-    for (int j = threadIdx.x; j < bins; j += 256) {
+    for (int j = threadIdx.x; j < bins; j += NT) {
         const float v = ws.val[j], p = ws.pdf[j];
         if (j < index) {
             const float qv = (step == 0.f ? (v / step) : floor_div_f32(v, step)) * step;
@@ -188,48 +201,57 @@ __device__ float candidate_loss(const SearchWs& ws, int bins, int index, int q, 
     }
     sq = wave_sum_d(sq);
     sc = wave_sum_d(sc);
+    constexpr int NW = NT / 64;
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         red[wv] = sq;
-        red[4 + wv] = sc;
+        red[NW + wv] = sc;
     }
     __syncthreads();
-    const double tq = red[0] + red[1] + red[2] + red[3];
-    const double tc = red[4] + red[5] + red[6] + red[7];
+    double tq = 0.0, tc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        tq += red[w];
+        tc += red[NW + w];
+    }
     __syncthreads();
     return (float)tq * dx + (float)tc * dx;
 }
 
-// phase 0: coarse scan, block b evaluates index b * (bins / 10)
-// phase 1: fine scan of [indices[max(tp-1,0)], indices[min(tp+1,10)]), block b evaluates start + b
-__global__ __launch_bounds__(256) void search_loss_kernel(float* ws_base, int bins, int q, int phase) {
+// coarse scan: block b evaluates index b * (bins / 10).  Eleven workgroups at most, so the launch lasts as long as one
+// candidate: 1024 threads share its bins.
+__global__ __launch_bounds__(1024) void search_coarse_kernel(float* ws_base, int bins, int q) {
+    __shared__ double red[32];
+    SearchWs ws = search_ws(ws_base, bins);
+    const int i = blockIdx.x * (bins / 10);
+    if (i >= bins) return;
+    const float l = candidate_loss<1024>(ws, bins, i, q, red);
+    if (threadIdx.x == 0) {
+        ws.coarse_loss[blockIdx.x] = l;
+        ws.coarse_idx[blockIdx.x] = i;
+    }
+}
+
+// fine scan of [indices[max(tp-1,0)], indices[min(tp+1,10)]), block b evaluates start + b (thousands of workgroups:
+// bound by throughput, 256 threads each)
+__global__ __launch_bounds__(256) void search_fine_kernel(float* ws_base, int bins, int q) {
     __shared__ double red[8];
     SearchWs ws = search_ws(ws_base, bins);
-    if (phase == 0) {
-        const int i = blockIdx.x * (bins / 10);
-        if (i >= bins) return;
-        const float l = candidate_loss(ws, bins, i, q, red);
-        if (threadIdx.x == 0) {
-            ws.coarse_loss[blockIdx.x] = l;
-            ws.coarse_idx[blockIdx.x] = i;
+    int tp = 0;
+    float best = ws.coarse_loss[0];
+    for (int j = 1; j < 11; ++j) {
+        const float l = ws.coarse_loss[j];
+        if (l < best) {  // first minimum wins, as torch.min does
+            best = l;
+            tp = j;
         }
-    } else {
-        int tp = 0;
-        float best = ws.coarse_loss[0];
-        for (int j = 1; j < 11; ++j) {
-            const float l = ws.coarse_loss[j];
-            if (l < best) {  // first minimum wins, as torch.min does
-                best = l;
-                tp = j;
-            }
-        }
-        const int start = ws.coarse_idx[max(tp - 1, 0)];
-        const int end = ws.coarse_idx[min(tp + 1, 10)];
-        const int i = start + (int)blockIdx.x;
-        if (i >= end) return;
-        const float l = candidate_loss(ws, bins, i, q, red);
-        if (threadIdx.x == 0) ws.total_loss[i] = l;
     }
+    const int start = ws.coarse_idx[max(tp - 1, 0)];
+    const int end = ws.coarse_idx[min(tp + 1, 10)];
+    const int i = start + (int)blockIdx.x;
+    if (i >= end) return;
+    const float l = candidate_loss<256>(ws, bins, i, q, red);
+    if (threadIdx.x == 0) ws.total_loss[i] = l;
 }
 
 // argmin (first occurrence) of total_loss; outputs alpha = val[idx], idx, scaling factor maxq / alpha.
@@ -284,9 +306,9 @@ static int launch_search(const uint32_t* hist, int num_bins, int num_bits, float
     SLIM_LAUNCH_CHECK();
     const int stride = num_bins / 10;
     const int ncoarse = (num_bins + stride - 1) / stride;  // 10 or 11 points
-    search_loss_kernel<<<ncoarse, 256, 0, st>>>(ws, num_bins, num_bits, 0);
+    search_coarse_kernel<<<ncoarse, 1024, 0, st>>>(ws, num_bins, num_bits);
     SLIM_LAUNCH_CHECK();
-    search_loss_kernel<<<2 * stride, 256, 0, st>>>(ws, num_bins, num_bits, 1);
+    search_fine_kernel<<<2 * stride, 256, 0, st>>>(ws, num_bins, num_bits);
     SLIM_LAUNCH_CHECK();
     search_argmin_kernel<<<1, 1024, 0, st>>>(ws, num_bins, num_bits, alpha_out, idx_out, sf_out);
     SLIM_LAUNCH_CHECK();

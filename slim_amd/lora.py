@@ -99,17 +99,9 @@ def deflate_outliers(E, Et, outliers, out=None):
     of Q_O are zero.  The outlier columns of E' are not zeroed: they hold what bf16 rounding of Q_O and C left of those
     columns, which the fit can still pick up."""
     cols, t = outliers
-    # each column normalised first (their norms differ by orders of magnitude); the padding columns are zeroed, and a
-    # zero column stays zero through Newton-Schulz steps, so the basis spans the real outlier columns only
-    EO = torch.index_select(E, 1, cols).float()
-    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
-    EO[:, t:] = 0
-    EO = EO.to(torch.bfloat16).contiguous()
-    # the normalised columns are close to orthogonal already (random directions in N dimensions): two quintic and
-    # three cubic Newton-Schulz steps bring them to an orthonormal basis of the same span
-    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
-    UO[:, t:] = 0
-    UOt[t:] = 0
+    # the basis from the Cholesky factor of the normalised columns' Gram matrix (ops.outlier_basis); padding columns zero
+    UO, UOt = ops.outlier_basis(Et, cols, t)
+    info_o = torch.zeros(64, dtype=torch.int32, device=E.device)
     _, _, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
     E2 = ops.lowrank_residual(UO, Ct, E, None, out=out)
     return E2, UO, Ct, info_o
@@ -406,6 +398,43 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     c.level_hint = int(getattr(activations, "fit_level_hint", 0) or 0)
     c.fit = None
     c.deflated = None
+    return c
+
+
+def prepare_fusable(module, quantizer, slim_lora, prune_lora, separate_lora, quantize_first, scale_important_weights, prune_n):
+    """True when add_lora_prepare_fused covers this layer's recipe: an N:M (or precomputed) mask, no quantiser or a
+    per-tensor one applied to the dense weight, separate unpruned adapters."""
+    W = module.weight.data
+    return (W.dtype == torch.bfloat16 and W.is_cuda and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0
+            and (prune_n > 0 or hasattr(module.weight, "mask"))
+            and (quantizer is None or (not quantizer.block_quantization and quantize_first))
+            and separate_lora and not prune_lora and not scale_important_weights)
+
+
+def add_lora_prepare_fused(module, prune_n, prune_m, rank_ratio, slim_lora, activations, quantizer, lora_tile_size=None,
+                           W_mask=None):
+    """add_lora_prepare and add_lora_deflate with the Wanda mask before them as ONE library call (ops.lora_prepare): the
+    statistics' square root, the N:M mask (unless W_mask is given), the first scale search, the error matrix and its
+    transpose, and the split-off of the outlier columns.  activations must carry has_zero / outliers / scale_spread
+    (prune.block_stats).  Returns the LoraContext that add_lora_fit* and add_lora_finish take."""
+    c = LoraContext()
+    c.module, c.quantizer, c.separate = module, quantizer, True
+    c.prune_lora, c.lora_left_mask = False, None
+    c.W = module.weight.data.contiguous()
+    N, K = c.W.shape
+    c.bits = quantizer.num_bits if quantizer is not None else 4
+    use_slim = bool(slim_lora) and not activations.has_zero                     # lora.py:139
+    rank = lora_rank((N, K), rank_ratio, lora_tile_size)
+    c.rank = min(rank, min(N, K))
+    c.outliers, c.spread = (activations.outliers, activations.scale_spread) if use_slim else (None, 1.0)
+    deflate = c.outliers if fit_plan(N, K, c.rank, c.outliers)[3] else None
+    mode = 0 if quantizer is None else (1 if quantizer.slim_quant else 2)
+    out = ops.lora_prepare(c.W, activations.scaler_row, prune_n, prune_m, W_mask, mode, c.bits, use_slim, deflate)
+    c.W_mask, c.E, c.Et = out["mask"], out["E"], out["Et"]
+    c.s = out["s"] if use_slim else None
+    c.level_hint = int(getattr(activations, "fit_level_hint", 0) or 0)
+    c.fit = None
+    c.deflated = out["deflated"]
     return c
 
 

@@ -638,6 +638,52 @@ def lora_finish(U, L, W, mask, rank, quant_mode, num_bits, prescale):
     return Wq, sf, left, right
 
 
+def outlier_basis(Et, cols, t):
+    """(UO [N, tp], UOt [tp, N]): an orthonormal basis of the columns cols[:t] of E, read as rows of Et [K, N] (bf16); cols int32,
+    padded to tp entries (a multiple of 8, at most 64); the columns >= t of the basis are zero."""
+    Et = _chk(Et, BF16, "Et")
+    cols = _chk(cols, torch.int32, "cols")
+    N, tp = Et.shape[1], cols.numel()
+    UO = torch.empty(N, tp, dtype=BF16, device=Et.device)
+    UOt = torch.empty(tp, N, dtype=BF16, device=Et.device)
+    ws = _ws(_lib.query("slim_outlier_basis_workspace_bytes", tp), Et.device)
+    _lib.call("slim_outlier_basis", _p(Et), N, _p(cols), int(t), tp, _p(UO), _p(UOt), _p(ws), ws.numel(), _stream())
+    return UO, UOt
+
+
+def lora_prepare(W, scaler_row, prune_n, prune_m, mask, quant_mode, num_bits, scale_error, outliers=None):
+    """The head of add_lora in one call (slim_lora_prepare).  mask: a bool [N, K] tensor to use, or None to compute the N:M
+    mask from |W| * sqrt(scaler_row).  outliers: (int32 indices padded to a multiple of 8, number t of real ones) or None.
+    Returns dict(mask, s, sf, E, Et, deflated) with deflated = (E2, E2t, UO, Ct, info words) or None."""
+    W = _chk(W, BF16, "W")
+    scaler_row = _chk(scaler_row, torch.float32, "scaler_row")
+    N, K = W.shape
+    dev = W.device
+    given = mask is not None
+    mask = _chk(mask, torch.bool, "mask") if given else torch.empty(N, K, dtype=torch.bool, device=dev)
+    s = torch.empty(K, dtype=torch.float32, device=dev)
+    sf = torch.empty(1, dtype=torch.float32, device=dev) if quant_mode else None
+    E = torch.empty(N, K, dtype=BF16, device=dev)
+    Et = torch.empty(K, N, dtype=BF16, device=dev)
+    t, tp, idx = 0, 0, None
+    UO = UOt = Ct = E2 = E2t = info = None
+    if outliers is not None and outliers[1] > 0:
+        idx, t = outliers
+        idx = _chk(idx, torch.int32, "outlier indices")
+        tp = idx.numel()
+        UO = torch.empty(N, tp, dtype=BF16, device=dev)
+        UOt = torch.empty(tp, N, dtype=BF16, device=dev)
+        Ct = torch.empty(K, tp, dtype=BF16, device=dev)
+        E2 = torch.empty(N, K, dtype=BF16, device=dev)
+        E2t = torch.empty(K, N, dtype=BF16, device=dev)
+        info = torch.zeros(64, dtype=torch.int32, device=dev)
+    ws = _ws(_lib.query("slim_lora_prepare_workspace_bytes", N, K, tp), dev)
+    _lib.call("slim_lora_prepare", _p(W), _p(scaler_row), N, K, 0 if given else int(prune_n), int(prune_m), _p(mask), int(quant_mode),
+              int(num_bits), int(bool(scale_error)), _p(s), _p(sf), _p(E), _p(Et), _p(idx), int(t), int(tp), _p(UO), _p(UOt), _p(Ct),
+              _p(E2), _p(E2t), _p(ws), ws.numel(), _stream())
+    return dict(mask=mask, s=s, sf=sf, E=E, Et=Et, deflated=(E2, E2t, UO, Ct, info) if t else None, UOt=UOt)
+
+
 def residual_weight(W, LR, mask, want_hist=False):
     W = _chk(W, BF16, "W")
     LR = _chk(LR, BF16, "LR")

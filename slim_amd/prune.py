@@ -54,6 +54,9 @@ GROUP_STREAM_IDS = [int(x) for x in os.environ.get("SLIM_GROUP_STREAMS", "0,1,2,
 # several GPUs: cut every linear of a block into row (or column) blocks over all ranks (sharded.py) where the recipe
 # allows it; SLIM_SHARD_LINEARS=0: whole linears on their owners
 SHARD_LINEARS = os.environ.get("SLIM_SHARD_LINEARS", "1") == "1"
+# the first phase of a linear (mask, first scale search, error matrix, split-off of outlier columns) as one library call
+# where the recipe allows (lora.prepare_fusable); SLIM_FUSED_PREPARE=0: the same steps as separate calls
+FUSED_PREPARE = os.environ.get("SLIM_FUSED_PREPARE", "1") == "1"
 _side_streams = {}
 
 
@@ -475,8 +478,21 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
 
             ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
             def prepare_and_deflate(idx):
-                prepare(idx)
-                add_lora_deflate(ctxs[idx])
+                name, lin, wrapped = items[idx]
+                if FUSED_PREPARE and _lora.prepare_fusable(lin, quantizer, slim_lora, prune_lora, separate_lora, quantize_first,
+                                                           scale_important_weights, prune_n):
+                    # mask, first scale search, error matrix and the split-off of the outlier columns as one library call
+                    if describe:
+                        describe(name)
+                    given = None
+                    if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
+                        given = lin.weight.mask.to(dev)
+                        del lin.weight.mask
+                    ctxs[idx] = _lora.add_lora_prepare_fused(lin, prune_n, prune_m, lora_rank, slim_lora, wrapped, quantizer, tile,
+                                                             given)
+                else:
+                    prepare(idx)
+                    add_lora_deflate(ctxs[idx])
                 return ctxs[idx].tensors()
 
             if PIPELINE_GROUPS and len(fit_groups) <= 4:

@@ -116,13 +116,10 @@ def _deflate(j, outliers, dev, group):
         local = (cols - j.lo).clamp(0, j.hi - j.lo - 1)
         EO.copy_(torch.index_select(j.E_s, 1, local).float() * own.reshape(1, -1))
     parallel.all_reduce(EO, group)              # every entry comes from exactly one rank
-    EO = EO / EO.norm(dim=0, keepdim=True).clamp_min(1e-30)
-    EO[:, t:] = 0
-    EO = EO.to(torch.bfloat16).contiguous()
-    UO, UOt, info_o = ops.orthonormalize(EO, ns_quintic=2, ns_cubic=3)
-    UO[:, t:] = 0
-    UOt[t:] = 0
-    j.info_o = info_o
+    # the gathered columns are bf16 values (every entry comes from one rank's block of E): the single-GPU basis routine
+    # on them gives every rank the basis a single GPU computes
+    UO, UOt = ops.outlier_basis(EO.t().contiguous().to(torch.bfloat16), torch.arange(tp, dtype=torch.int32, device=dev), t)
+    j.info_o = torch.zeros(64, dtype=torch.int32, device=dev)
     if j.right:
         # C = Q_O^T E [tp, K]: a sum over the row blocks
         C32 = ops.gemm_nt(UOt[:, j.lo:j.hi].contiguous(), j.Et_s, out_f32=True)[0]

@@ -86,6 +86,18 @@ def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
     return Q, Q.t().contiguous(), torch.zeros(64, dtype=torch.int32)
 
 
+def outlier_basis(Et, cols, t):
+    """Q_O = E_O D^-1 R^-1 from the Cholesky factor of the normalised columns' Gram matrix, as the library forms it."""
+    tp = cols.numel()
+    EO = Et.double()[cols[:t].long()].t()                     # [N, t]
+    dn = EO.norm(dim=0)
+    R = torch.linalg.cholesky((EO.t() @ EO) / (dn[:, None] * dn[None, :]), upper=True)
+    Q = torch.zeros(EO.shape[0], tp, dtype=torch.float64)
+    Q[:, :t] = (EO / dn) @ torch.linalg.inv(R)
+    Q = Q.to(BF16)
+    return Q, Q.t().contiguous()
+
+
 def gramfit_iterate(C16, l, n_iter, seed=0, flags=0, cond_e=0):
     w, V = torch.linalg.eigh(C16.double())
     P = V[:, -l:].to(BF16).contiguous()
