@@ -29,6 +29,7 @@
 
 #define TD_THREADS 256
 #define TD_ROWS_PER_WAVE 2
+#define TW_CHUNK 16          // stored pivots / multipliers the twisted-factorisation kernel requests at a time
 
 struct TridiagArgs {
     float* A;      // [batch][n, n] symmetric, both triangles valid; destroyed
@@ -273,13 +274,25 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_step_kernel(TridiagArgs g)
 // ---- tridiagonal eigen-solver in double precision -------------------------------------------------------------------
 // Number of eigenvalues of tridiag(d, e) that are <= x (LAPACK dstebz's count: negative pivots of the LDL^T factorisation
 // of T - x I, a pivot smaller than pivmin in magnitude counted as negative).  e2[i] = e[i]^2.
+// 1 / x for the pivot recurrences below: the hardware's reciprocal estimate and two Newton steps (full double precision
+// for the normal, non-zero pivots these recurrences guard with pivmin / tiny), half the dependent instructions of an IEEE
+// division -- the recurrences are chains of n dependent divisions and nothing else
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Number of eigenvalues of tridiag(d, e) that are <= x (LAPACK dstebz's count: negative pivots of the LDL^T factorisation
+// of T - x I, a pivot smaller than pivmin in magnitude counted as negative).  e2[i] = e[i]^2.
 __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n, double x,
                                            double pivmin) {
     double q = d[0] - x;
     if (fabs(q) < pivmin) q = -pivmin;
     int cnt = q <= 0.0;
     for (int i = 1; i < n; ++i) {
-        q = d[i] - x - e2[i - 1] / q;
+        q = d[i] - x - e2[i - 1] * fast_rcp(q);
         if (fabs(q) < pivmin) q = -pivmin;
         cnt += q <= 0.0;
     }
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(256) void tri_multisect_kernel(TriEigArgs g) {
     for (int sweep = 0; sweep < 12; ++sweep) {
         const double w = hi - lo;
         if (w <= 2.0 * DBL_EPSILON * norm + 2.0 * pivmin) break;     // accuracy relative to the matrix, as the vectors need it
+        // (two shifts per lane, 129-fold per sweep, measured slower: 753 against 590 us -- a sweep is bound by fp64 issue)
         const double x = lo + w * ((double)(lane + 1) / 65.0);
         const int cnt = sturm_count(d, e2, n, x, pivmin);
         // eigenvalue k is the smallest x with count(x) >= k + 1: the first lane that reaches the count bounds it from above
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(64) void tri_twisted_kernel(TriEigArgs g) {
     for (int i = 0; i < n - 1; ++i) {
         if (fabs(dp) < tiny) dp = dp < 0.0 ? -tiny : tiny;
         zb[(int64_t)i * ldz] = dp;
-        const double l = e[i] / dp;
+        const double l = e[i] * fast_rcp(dp);
         lp[(int64_t)i * ldz] = l;
         dp = (d[i + 1] - lam) - l * e[i];
     }
@@ -415,20 +429,31 @@ __global__ __launch_bounds__(64) void tri_twisted_kernel(TriEigArgs g) {
             ++seen;
         }
         if (pass == 0) kbest = n - 1;
-        for (int i = n - 2; i >= 0; --i) {
-            if (fabs(dm) < tiny) dm = dm < 0.0 ? -tiny : tiny;
-            const double u = e[i] / dm;
-            if (pass == 0) um[(int64_t)i * ldz] = u;
-            dm = (d[i] - lam) - u * e[i];
-            const double gam = fabs(zb[(int64_t)i * ldz] + dm - (d[i] - lam));
-            if (pass == 0) {
-                if (gam < best) {
-                    best = gam;
-                    kbest = i;
+        // the forward pivots come back from memory TW_CHUNK at a time, all requested before the first is used: one trip to
+        // memory per chunk instead of one per step of the recurrence
+        for (int i0 = n - 2; i0 >= 0; i0 -= TW_CHUNK) {
+            double zf[TW_CHUNK];
+#pragma unroll
+            for (int c = 0; c < TW_CHUNK; ++c) zf[c] = i0 - c >= 0 ? zb[(int64_t)(i0 - c) * ldz] : 0.0;
+#pragma unroll
+            for (int c = 0; c < TW_CHUNK; ++c) {
+                const int i = i0 - c;
+                if (i >= 0) {
+                    if (fabs(dm) < tiny) dm = dm < 0.0 ? -tiny : tiny;
+                    const double u = e[i] * fast_rcp(dm);
+                    if (pass == 0) um[(int64_t)i * ldz] = u;
+                    dm = (d[i] - lam) - u * e[i];
+                    const double gam = fabs(zf[c] + dm - (d[i] - lam));
+                    if (pass == 0) {
+                        if (gam < best) {
+                            best = gam;
+                            kbest = i;
+                        }
+                    } else if (gam <= gbest * (1.0 + 1e-6) + tiny) {
+                        if (seen == dup) kbest = i;
+                        ++seen;
+                    }
                 }
-            } else if (gam <= gbest * (1.0 + 1e-6) + tiny) {
-                if (seen == dup) kbest = i;
-                ++seen;
             }
         }
         if (pass == 0) gbest = best;
@@ -437,22 +462,47 @@ __global__ __launch_bounds__(64) void tri_twisted_kernel(TriEigArgs g) {
     // the vector: 1 at the twist, multipliers outwards
     double z = 1.0, ss = 1.0;
     zb[(int64_t)kbest * ldz] = 1.0;
-    for (int i = kbest - 1; i >= 0; --i) {
-        z = -lp[(int64_t)i * ldz] * z;
-        zb[(int64_t)i * ldz] = z;
-        ss += z * z;
+    for (int i0 = kbest - 1; i0 >= 0; i0 -= TW_CHUNK) {
+        double m[TW_CHUNK];
+#pragma unroll
+        for (int c = 0; c < TW_CHUNK; ++c) m[c] = i0 - c >= 0 ? lp[(int64_t)(i0 - c) * ldz] : 0.0;
+#pragma unroll
+        for (int c = 0; c < TW_CHUNK; ++c) {
+            const int i = i0 - c;
+            if (i >= 0) {
+                z = -m[c] * z;
+                zb[(int64_t)i * ldz] = z;
+                ss += z * z;
+            }
+        }
     }
     z = 1.0;
-    for (int i = kbest; i < n - 1; ++i) {
-        z = -um[(int64_t)i * ldz] * z;
-        zb[(int64_t)(i + 1) * ldz] = z;
-        ss += z * z;
+    for (int i0 = kbest; i0 < n - 1; i0 += TW_CHUNK) {
+        double m[TW_CHUNK];
+#pragma unroll
+        for (int c = 0; c < TW_CHUNK; ++c) m[c] = i0 + c < n - 1 ? um[(int64_t)(i0 + c) * ldz] : 0.0;
+#pragma unroll
+        for (int c = 0; c < TW_CHUNK; ++c) {
+            const int i = i0 + c;
+            if (i < n - 1) {
+                z = -m[c] * z;
+                zb[(int64_t)(i + 1) * ldz] = z;
+                ss += z * z;
+            }
+        }
     }
     const bool finite = ss < DBL_MAX && ss == ss;
     if (!finite) atomicOr(g.info + bz * g.info_stride, 1);
     const double inv = finite ? 1.0 / sqrt(ss) : 0.0;
     float* Zc = g.Z + bz * n * ldz + col;
-    for (int i = 0; i < n; ++i) Zc[(int64_t)i * ldz] = (float)(zb[(int64_t)i * ldz] * inv);
+    for (int i0 = 0; i0 < n; i0 += TW_CHUNK) {
+        double m[TW_CHUNK];
+#pragma unroll
+        for (int c = 0; c < TW_CHUNK; ++c) m[c] = i0 + c < n ? zb[(int64_t)(i0 + c) * ldz] : 0.0;
+#pragma unroll
+        for (int c = 0; c < TW_CHUNK; ++c)
+            if (i0 + c < n) Zc[(int64_t)(i0 + c) * ldz] = (float)(m[c] * inv);
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
