@@ -353,9 +353,16 @@ int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t K, int r8,
  * (UO^T E)^T, E2 = E - UO Ct^T and E2t its transpose: what the randomized fit of slim_lowrank_fit* then runs on.
  * slim_outlier_basis is the basis step alone: the columns cols[0 .. t) of E are rows of Et [K, N]; the basis is E_O D^-1 R^-1
  * with D the column norms and R the Cholesky factor of the normalised columns' Gram matrix (double precision). */
+/* Factors of a layer whose t outlier columns were split off: U [N, r8] = [UO[:, :t] | fitU[:, :rank - t] | 0], Ut its
+ * transpose, L [K, r8] = [Ct[:, :t] / bf16(s) row-wise (s may be NULL) | fitL[:, :rank - t] | 0].  No counterpart in the
+ * reference. */
+int slim_lora_assemble(const void* UO, const void* Ct, const float* s, const void* fitU, const void* fitL, int64_t N, int64_t K,
+                       int tp, int t, int rf, int rank, int r8, void* U, void* Ut, void* L, void* stream);
 int64_t slim_outlier_basis_workspace_bytes(int tp);
 int slim_outlier_basis(const void* Et_bf16, int64_t N, const int32_t* cols, int t, int tp, void* UO, void* UOt, void* workspace,
                        int64_t workspace_bytes, void* stream);
+/* Ct [K, tp] = bf16(Et UOt^T) (fp32 accumulation): every column of E projected on the basis of slim_outlier_basis. */
+int slim_outlier_project(const void* Et_bf16, const void* UOt, int64_t K, int64_t N, int tp, void* Ct, void* stream);
 int64_t slim_lora_prepare_workspace_bytes(int64_t N, int64_t K, int tp);
 int slim_lora_prepare(const void* W_bf16, const float* scaler_row, int64_t N, int64_t K, int prune_n, int prune_m, uint8_t* mask,
                       int quant_mode, int num_bits, int scale_error, float* s_out, float* sf_out, void* E_bf16, void* Et_bf16,

@@ -1043,6 +1043,44 @@ extern "C" int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t
     return SLIM_OK;
 }
 
+// ---- factors of a fit with split-off outlier columns, assembled -----------------------------------------------------------
+// out [rows, r8]: columns < t from `exact` [rows, tp] (each row divided by bf16(s[row]) when s is given, the arithmetic of
+// scale_rows_kernel), columns t .. rank - 1 from the first rank - t columns of `fit` [rows, rf], the rest zero
+__global__ void assemble_factor_kernel(const bf16_t* __restrict__ exact, int tp, int t, const float* __restrict__ s,
+                                       const bf16_t* __restrict__ fit, int rf, int rank, int r8, int64_t rows,
+                                       bf16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * r8) return;
+    const int64_t row = i / r8;
+    const int j = (int)(i - row * r8);
+    bf16_t v = 0;
+    if (j < t) {
+        v = exact[row * tp + j];
+        if (s) v = f32_to_bf16(bf16_to_f32(v) / round_bf16(s[row]));
+    } else if (j < rank) {
+        v = fit[row * rf + (j - t)];
+    }
+    out[i] = v;
+}
+
+// U [N, r8], Ut [r8, N], L [K, r8] of a layer whose t outlier columns were split off before the randomized fit: the exact
+// part (UO [N, tp], Ct [K, tp], Ct's rows divided by bf16(s) as the fit divides its own factor) in the first t columns, the
+// fit's first rank - t columns (fitU [N, rf], fitL [K, rf]) behind them, columns >= rank zero
+extern "C" int slim_lora_assemble(const void* UO, const void* Ct, const float* s, const void* fitU, const void* fitL, int64_t N,
+                                  int64_t K, int tp, int t, int rf, int rank, int r8, void* U, void* Ut, void* L, void* stream) {
+    SLIM_REQUIRE(UO && Ct && fitU && fitL && U && Ut && L, "slim_lora_assemble: null pointer");
+    SLIM_REQUIRE(N > 0 && K > 0 && t > 0 && t <= tp && rank > t && rank - t <= rf && rank <= r8 && r8 % 8 == 0,
+                 "slim_lora_assemble: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    assemble_factor_kernel<<<(unsigned)ceil_div64(N * r8, 256), 256, 0, st>>>((const bf16_t*)UO, tp, t, nullptr, (const bf16_t*)fitU, rf,
+                                                                             rank, r8, N, (bf16_t*)U);
+    SLIM_LAUNCH_CHECK();
+    assemble_factor_kernel<<<(unsigned)ceil_div64(K * r8, 256), 256, 0, st>>>((const bf16_t*)Ct, tp, t, s, (const bf16_t*)fitL, rf, rank,
+                                                                             r8, K, (bf16_t*)L);
+    SLIM_LAUNCH_CHECK();
+    return slim_transpose_bf16(U, N, r8, Ut, stream);
+}
+
 // ---- the head of add_lora in one call ------------------------------------------------------------------------------------
 // Outlier columns of the error matrix (input channels whose saliency scale is far above the median) are split off before
 // the randomized fit: with Q_O an orthonormal basis of those t columns, E = Q_O (Q_O^T E) + E'.  The columns are rows of
@@ -1148,6 +1186,57 @@ __global__ __launch_bounds__(256) void outlier_q_kernel(const bf16_t* __restrict
     }
 }
 
+// Ct [K, tp] = bf16(Et UOt^T): the projection of every column of E (a row of Et [K, N]) on the tp basis vectors (rows of
+// UOt [tp, N]).  A product with tp <= 64 output columns: a wave per row of Et streams the row once (16 bytes per lane and
+// step) against the basis, which stays in cache; the tile GEMM would run one 128-wide tile column for it.
+template <int TP>
+__global__ __launch_bounds__(256) void outlier_project_kernel(const bf16_t* __restrict__ Et, const bf16_t* __restrict__ UOt, int64_t K,
+                                                              int64_t N, bf16_t* __restrict__ Ct) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const bf16_t* row = Et + k * N;
+    float acc[TP];
+#pragma unroll
+    for (int c = 0; c < TP; ++c) acc[c] = 0.f;
+    for (int64_t n = (int64_t)lane * 8; n < N; n += 512) {
+        const u16x8 e = *(const u16x8*)(row + n);
+        float ef[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ef[u] = bf16_to_f32(e[u]);
+#pragma unroll
+        for (int c = 0; c < TP; ++c) {
+            const u16x8 b = *(const u16x8*)(UOt + (int64_t)c * N + n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[c] += ef[u] * bf16_to_f32(b[u]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < TP; ++c) acc[c] = wave_sum(acc[c]);
+    if (lane < TP) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < TP; ++c)
+            if (lane == c) v = acc[c];
+        Ct[k * TP + lane] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int slim_outlier_project(const void* Et, const void* UOt, int64_t K, int64_t N, int tp, void* Ct, void* stream) {
+    SLIM_REQUIRE(Et && UOt && Ct && K > 0 && N > 0 && N % 8 == 0, "slim_outlier_project: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(K, 4);
+    if (tp == 8) outlier_project_kernel<8><<<grid, 256, 0, st>>>((const bf16_t*)Et, (const bf16_t*)UOt, K, N, (bf16_t*)Ct);
+    else if (tp == 16) outlier_project_kernel<16><<<grid, 256, 0, st>>>((const bf16_t*)Et, (const bf16_t*)UOt, K, N, (bf16_t*)Ct);
+    else {
+        // wider bases (rare: more than 16 outlier channels): the tile GEMM, transposed output only
+        SLIM_REQUIRE(tp > 0 && tp % 8 == 0 && tp <= 64, "slim_outlier_project: tp must be a multiple of 8, at most 64");
+        return slim_gemm_nt_bf16(UOt, N, Et, N, tp, (int)K, (int)N, 1.f, 0.f, nullptr, 0, nullptr, 0, Ct, tp, stream);
+    }
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 static inline int64_t prepare_search_bins(int64_t numel) { return numel / 1000 < 512 ? 512 : (numel / 1000 > 20000 ? 20000 : numel / 1000); }
 
 extern "C" int64_t slim_outlier_basis_workspace_bytes(int tp) {
@@ -1214,8 +1303,7 @@ extern "C" int slim_lora_prepare(const void* W, const float* scaler_row, int64_t
     CHK(slim_transpose_bf16(E, N, K, Et, stream));
     if (t == 0) return SLIM_OK;
     CHK(slim_outlier_basis(Et, N, outlier_idx, t, tp, UO, UOt, basis_ws, slim_outlier_basis_workspace_bytes(tp), stream));
-    // Ct [K, tp] = (UOt Et^T)^T: the product's transposed output only
-    CHK(slim_gemm_nt_bf16(UOt, N, Et, N, tp, (int)K, (int)N, 1.f, 0.f, nullptr, 0, nullptr, 0, Ct, tp, stream));
+    CHK(slim_outlier_project(Et, UOt, K, N, tp, Ct, stream));
     CHK(slim_lowrank_residual(UO, Ct, (int)N, (int)K, tp, E, nullptr, E2, nullptr, stream));
     CHK(slim_transpose_bf16(E2, N, K, E2t, stream));
     return SLIM_OK;

@@ -102,7 +102,7 @@ def deflate_outliers(E, Et, outliers, out=None):
     # the basis from the Cholesky factor of the normalised columns' Gram matrix (ops.outlier_basis); padding columns zero
     UO, UOt = ops.outlier_basis(Et, cols, t)
     info_o = torch.zeros(64, dtype=torch.int32, device=E.device)
-    _, _, Ct = ops.gemm_nt(UOt, Et, out_bf16=True, out_t=True)
+    Ct = ops.outlier_project(Et, UOt)
     E2 = ops.lowrank_residual(UO, Ct, E, None, out=out)
     return E2, UO, Ct, info_o
 
@@ -117,14 +117,10 @@ def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, i
             fitUt[rank:] = 0
             fitL[:, rank:] = 0
         return fitU, fitUt, fitL, fit_info
-    LO = ops.scale_rows(Ct, s) if s is not None else Ct
-    U = torch.zeros(N, r8, dtype=fitU.dtype, device=fitU.device)
-    L = torch.zeros(K, r8, dtype=fitU.dtype, device=fitU.device)
-    U[:, :t] = UO[:, :t]
-    U[:, t:rank] = fitU[:, :rank - t]
-    L[:, :t] = LO[:, :t]
-    L[:, t:rank] = fitL[:, :rank - t]
-    return U, ops.transpose(U), L, torch.cat([info_o, fit_info])
+    # the status words of the outlier basis are all zero by construction (a vanishing pivot drops its column): the fit's own
+    # words are the layer's
+    U, Ut, L = ops.lora_assemble(UO, Ct, s, fitU, fitL, t, rank, r8)
+    return U, Ut, L, fit_info
 
 
 def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):

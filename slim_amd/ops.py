@@ -638,6 +638,31 @@ def lora_finish(U, L, W, mask, rank, quant_mode, num_bits, prescale):
     return Wq, sf, left, right
 
 
+def outlier_project(Et, UOt):
+    """Ct [K, tp] = bf16(Et @ UOt.T): the columns of E projected on the outlier basis (slim_outlier_project)."""
+    Et, UOt = _chk(Et, BF16, "Et"), _chk(UOt, BF16, "UOt")
+    K, N = Et.shape
+    tp = UOt.shape[0]
+    Ct = torch.empty(K, tp, dtype=BF16, device=Et.device)
+    _lib.call("slim_outlier_project", _p(Et), _p(UOt), K, N, tp, _p(Ct), _stream())
+    return Ct
+
+
+def lora_assemble(UO, Ct, s, fitU, fitL, t, rank, r8):
+    """(U [N, r8], Ut [r8, N], L [K, r8]) of slim_lora_assemble: the exact part of the split-off outlier columns in front of
+    the randomized fit's factors."""
+    UO, Ct, fitU, fitL = _chk(UO, BF16, "UO"), _chk(Ct, BF16, "Ct"), _chk(fitU, BF16, "fitU"), _chk(fitL, BF16, "fitL")
+    N, tp = UO.shape
+    K, rf = fitL.shape
+    dev = UO.device
+    U = torch.empty(N, r8, dtype=BF16, device=dev)
+    Ut = torch.empty(r8, N, dtype=BF16, device=dev)
+    L = torch.empty(K, r8, dtype=BF16, device=dev)
+    _lib.call("slim_lora_assemble", _p(UO), _p(Ct), _p(s), _p(fitU), _p(fitL), N, K, tp, int(t), rf, int(rank), int(r8), _p(U), _p(Ut),
+              _p(L), _stream())
+    return U, Ut, L
+
+
 def outlier_basis(Et, cols, t):
     """(UO [N, tp], UOt [tp, N]): an orthonormal basis of the columns cols[:t] of E, read as rows of Et [K, N] (bf16); cols int32,
     padded to tp entries (a multiple of 8, at most 64); the columns >= t of the basis are zero."""

@@ -285,8 +285,13 @@ def check_fit_status(items, levels=None):
              if getattr(lin, "lora_fit_info", None) is not None]
     if not named:
         return {}
-    flags = torch.stack([torch.stack([info[:-2].ne(0).any().to(torch.int32), info[-1].to(torch.int32), info[-2].to(torch.int32)])
-                         for _, _, info in named]).cpu().tolist()
+    # one stacked tensor and a handful of launches for the whole block (per-linear reductions cost the host more than the GPU)
+    words = torch.stack([info.reshape(-1)[-64:].to(torch.int32) for _, _, info in named])
+    extra = [info.reshape(-1)[:-64].ne(0).any() for _, _, info in named if info.numel() > 64]
+    flags = torch.cat([words[:, :-2].ne(0).any(1, keepdim=True).to(torch.int32), words[:, -1:], words[:, -2:-1]], 1)
+    if extra:
+        flags[[i for i, (_, _, info) in enumerate(named) if info.numel() > 64], 0] |= torch.stack(extra).to(torch.int32)
+    flags = flags.cpu().tolist()
     failed = [(name, info[:-2].cpu().tolist()) for (_, name, info), f in zip(named, flags) if f[0]]
     if failed:
         from ._lib import SlimHipError, ERR_SOLVER
