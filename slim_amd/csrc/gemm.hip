@@ -61,7 +61,7 @@ __device__ __forceinline__ void store_tile(bf16_t* lds, const u16x8 (&r)[ROWS * 
 
 // Origin of this workgroup's output tile, and the batch offsets applied to the argument block.
 template <int BM, int BN>
-__device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, int& row0, int& col0) {
+__device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, const GemmArgs& gin, int& row0, int& col0) {
     // XCD-aware tile order: consecutive hardware workgroup ids round-robin over the 8 XCDs, so give
     // each XCD a contiguous run of tiles (neighbouring tiles share an A or B panel in that XCD's L2).
     const int nwg = gridDim.x;
@@ -94,8 +94,19 @@ __device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, int& row0, int& co
 
     if (g.batch > 1) {     // strided batch: blockIdx.z selects the problem
         const int64_t bz = blockIdx.z;
-        g.A += bz * g.sA;
-        g.B += bz * g.sB;
+        if (g.nptr) {
+            // operands in separate allocations.  They are read from the kernel's argument block itself (gin), not from the
+            // private copy the kernel modifies: the compiler turns the selection into an index, and an indexed private copy
+            // would live in scratch memory
+            const int z = (int)bz;
+            g.A = z == 0 ? gin.Ap0 : z == 1 ? gin.Ap1 : z == 2 ? gin.Ap2 : gin.Ap3;
+            g.B = z == 0 ? gin.Bp0 : z == 1 ? gin.Bp1 : z == 2 ? gin.Bp2 : gin.Bp3;
+            g.lda = g.ldb = z == 0 ? gin.ldp0 : z == 1 ? gin.ldp1 : z == 2 ? gin.ldp2 : gin.ldp3;
+            g.Kd = z == 0 ? gin.Kdp0 : z == 1 ? gin.Kdp1 : z == 2 ? gin.Kdp2 : gin.Kdp3;
+        } else {
+            g.A += bz * g.sA;
+            g.B += bz * g.sB;
+        }
         if (g.C32) g.C32 += bz * g.sC32;
         if (g.C16) g.C16 += bz * g.sC16;
         if (g.Ct16) g.Ct16 += bz * g.sCt;
@@ -365,15 +376,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
 // summary separates them the way the in-library timer does; the code is identical.
 enum { FAM_GRAM, FAM_SMALL, FAM_APPLY, FAM_SKETCH, FAM_BIG, FAM_RESIDUAL, FAM_COUNT };
 template <int FAMILY, int FM, int FN, int BKT = 64>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs gin) {
     constexpr int BM = 32 * FM, BN = 32 * FN, STRIDE = BKT + LDS_PAD;
+    GemmArgs g = gin;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     // buffer b: A tile at smem + b * (BM + BN) * STRIDE, B tile right after it
     auto As = [&](int b) { return smem + b * (BM + BN) * STRIDE; };
     auto Bs = [&](int b) { return smem + b * (BM + BN) * STRIDE + BM * STRIDE; };
 
     int row0, col0;
-    gemm_tile_origin<BM, BN>(g, row0, col0);
+    gemm_tile_origin<BM, BN>(g, gin, row0, col0);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -624,6 +636,17 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                  "slim_gemm_nt_bf16: Ct must be 8-byte aligned and cannot be combined with beta");
     SLIM_REQUIRE(!g.poly_G || (g.C16 && !g.C32 && !g.Ct16 && !g.Wn && g.splits <= 1 && g.beta == 0.f && g.M == g.N),
                  "slim_gemm_nt_bf16: the polynomial epilogue writes C_bf16 only, of a square product");
+    SLIM_REQUIRE(g.nptr == 0 || (g.nptr == g.batch && g.nptr <= GEMM_MAX_PTRS && g.splits <= 1), "slim_gemm_nt_bf16: bad pointer batch");
+    {
+        const bf16_t* ap[4] = {g.Ap0, g.Ap1, g.Ap2, g.Ap3};
+        const bf16_t* bp[4] = {g.Bp0, g.Bp1, g.Bp2, g.Bp3};
+        const int64_t ld[4] = {g.ldp0, g.ldp1, g.ldp2, g.ldp3};
+        const int kd[4] = {g.Kdp0, g.Kdp1, g.Kdp2, g.Kdp3};
+        for (int z = 0; z < g.nptr; ++z)
+            SLIM_REQUIRE(ap[z] && bp[z] && kd[z] > 0 && kd[z] % 8 == 0 && ld[z] % 8 == 0 && ld[z] >= kd[z] &&
+                             ((uintptr_t)ap[z] % 16) == 0 && ((uintptr_t)bp[z] % 16) == 0,
+                         "slim_gemm_nt_bf16: bad operand in a pointer batch");
+    }
     const int batch = g.batch > 1 ? g.batch : 1;
     SLIM_REQUIRE(batch <= 65535 && (batch == 1 || (!g.Wn && g.beta == 0.f)), "slim_gemm_nt_bf16: bad batch arguments");
     const int mx = g.M > g.N ? g.M : g.N, mn = g.M < g.N ? g.M : g.N;

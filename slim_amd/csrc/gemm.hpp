@@ -3,6 +3,8 @@
 #pragma once
 #include "common.hpp"
 
+#define GEMM_MAX_PTRS 4
+
 struct GemmArgs {
     const bf16_t* A = nullptr;
     int64_t lda = 0;
@@ -34,6 +36,24 @@ struct GemmArgs {
     // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
     int batch = 1;
     int64_t sA = 0, sB = 0, sC32 = 0, sC16 = 0, sCt = 0, sSlab = 0;
+    // batch of problems whose operands are separate allocations (nptr = batch, at most GEMM_MAX_PTRS): problem z reads
+    // Ap<z> / Bp<z> with row stride ldp<z> (both operands) and reduction length Kdp<z>; M, N and the outputs (strided as
+    // above) are common.  A == Ap0 etc. for the host-side checks.
+    // (separate scalar members, not arrays: an array in the argument block that a kernel indexes by blockIdx moves the whole
+    // block into scratch memory)
+    int nptr = 0;
+    const bf16_t *Ap0 = nullptr, *Ap1 = nullptr, *Ap2 = nullptr, *Ap3 = nullptr;
+    const bf16_t *Bp0 = nullptr, *Bp1 = nullptr, *Bp2 = nullptr, *Bp3 = nullptr;
+    int64_t ldp0 = 0, ldp1 = 0, ldp2 = 0, ldp3 = 0;
+    int Kdp0 = 0, Kdp1 = 0, Kdp2 = 0, Kdp3 = 0;
+    void set_problem(int z, const bf16_t* a, const bf16_t* b, int64_t ld, int kd) {     // host side
+        switch (z) {
+            case 0: Ap0 = a, Bp0 = b, ldp0 = ld, Kdp0 = kd; break;
+            case 1: Ap1 = a, Bp1 = b, ldp1 = ld, Kdp1 = kd; break;
+            case 2: Ap2 = a, Bp2 = b, ldp2 = ld, Kdp2 = kd; break;
+            default: Ap3 = a, Bp3 = b, ldp3 = ld, Kdp3 = kd; break;
+        }
+    }
     // optional fused epilogue of a Newton-Schulz step: with acc = G G, C16 = bf16(c * (a I + b c^2 G + q c^4 acc)),
     // c = *poly_scal (1 when NULL); needs M == N, no other output form
     const float* poly_G = nullptr;

@@ -1486,30 +1486,70 @@ extern "C" int slim_lowrank_fit_front_group(const void* const* E, const void* co
     const int64_t sP = Dm * l, sZ = Dxm * l, sG = (int64_t)l * l, sC = Dm * Dm, sSk = (int64_t)SKETCH_MAX_SPLITS * l * Dxm;
     float* sk_slab = (flags & SLIM_FIT_NO_SKETCH_SPLIT) ? nullptr : w.sketch_slab;
     if (flags & SLIM_FIT_NO_SKETCH_SPLIT) w.gram_cap = GRAM_SPLITS_SHARED_CHIP;
+    bool same_dx = true;
     for (int b = 0; b < batch; ++b) {
         SLIM_REQUIRE(E[b] && Et[b], "slim_lowrank_fit_front_group: null operand");
-        const bool right = Ks[b] <= Ns[b];
-        const int64_t Dx = right ? Ns[b] : Ks[b];
-        GemmArgs g;            // C = E^T E (operand E^T [K, N]) or E E^T (operand E [N, K])
-        g.A = g.B = (const bf16_t*)(right ? Et[b] : E[b]);
-        g.lda = g.ldb = Dx;
+        same_dx = same_dx && (Ks[b] <= Ns[b] ? Ns[b] : Ks[b]) == (Ks[0] <= Ns[0] ? Ns[0] : Ks[0]);
+    }
+    // C = E^T E (operand E^T [K, N]) or E E^T (operand E [N, K]) per member.  The members' matrices are separate
+    // allocations: up to GEMM_MAX_PTRS of them go into one launch (their reduction lengths may differ), so that the tiles of
+    // all members share the waves over the chip instead of every member ending with a partly filled one.
+    for (int b0 = 0; b0 < batch; b0 += GEMM_MAX_PTRS) {
+        const int nb = batch - b0 < GEMM_MAX_PTRS ? batch - b0 : GEMM_MAX_PTRS;
+        GemmArgs g;
+        for (int z = 0; z < nb; ++z) {
+            const int b = b0 + z;
+            const bool right = Ks[b] <= Ns[b];
+            const bf16_t* op = (const bf16_t*)(right ? Et[b] : E[b]);
+            const int64_t dx = right ? Ns[b] : Ks[b];
+            g.set_problem(z, op, op, dx, (int)dx);
+        }
+        g.A = g.B = g.Ap0;
+        g.lda = g.ldb = g.ldp0;
+        g.Kd = g.Kdp0;
         g.M = g.N = (int)Dm;
-        g.Kd = (int)Dx;
-        g.C16 = g.Ct16 = w.C16 + b * sC;
+        g.C16 = g.Ct16 = w.C16 + b0 * sC;
         g.ldc16 = g.ldct = Dm;
+        g.sC16 = g.sCt = sC;
         g.sym = 1;
+        if (nb > 1) {
+            g.batch = g.nptr = nb;
+        }
         CHK(slim_gemm_launch(g, stream));
     }
     int a = 0, ninfo = 0;
     CHK(gram_iterate(w.B, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond, w, sk_slab, sSk, stream, &a, &ninfo));
+    // the projections Z^T = P^T E^T (or P^T E): members with one long dimension, un-split, as one launch (operands of the
+    // members in separate allocations, outputs strided in the workspace); otherwise member by member
+    const bool proj_batched = same_dx && !sk_slab && batch > 1 && batch <= GEMM_MAX_PTRS;
+    if (proj_batched) {
+        const int64_t Dx = Ks[0] <= Ns[0] ? Ns[0] : Ks[0];
+        GemmArgs g;
+        for (int z = 0; z < batch; ++z)
+            g.set_problem(z, w.B[a].Xt + z * sP, (const bf16_t*)(Ks[z] <= Ns[z] ? E[z] : Et[z]), Dm, (int)Dm);
+        g.A = g.Ap0;
+        g.B = g.Bp0;
+        g.lda = g.ldb = Dm;
+        g.M = l;
+        g.N = (int)Dx;
+        g.Kd = (int)Dm;
+        g.C16 = w.A[0].Xt;
+        g.ldc16 = Dx;
+        g.Ct16 = w.A[0].X;
+        g.ldct = l;
+        g.sC16 = g.sCt = sZ;
+        g.batch = g.nptr = batch;
+        CHK(slim_gemm_launch(g, stream));
+    }
     for (int b = 0; b < batch; ++b) {
         const bool right = Ks[b] <= Ns[b];
         const int64_t Dx = right ? Ns[b] : Ks[b];
         FitWs m = member_ws(w, b, l);
         bf16_t* Z = w.A[0].X + b * sZ;
         bf16_t* Zt = w.A[0].Xt + b * sZ;
-        CHK(nt(1, w.B[a].Xt + b * sP, Dm, 0, (const bf16_t*)(right ? E[b] : Et[b]), Dm, 0, l, (int)Dx, (int)Dm, nullptr, Zt, Dx, Z, l,
-               stream, sk_slab ? sk_slab + b * sSk : nullptr, sSk));
+        if (!proj_batched)
+            CHK(nt(1, w.B[a].Xt + b * sP, Dm, 0, (const bf16_t*)(right ? E[b] : Et[b]), Dm, 0, l, (int)Dx, (int)Dm, nullptr, Zt, Dx, Z, l,
+                   stream, sk_slab ? sk_slab + b * sSk : nullptr, sSk));
         CHK(gram(Zt, Dx, l, m, nullptr, stream));
     }
     SLIM_HIP(hipMemcpyAsync(M_out, w.G, (size_t)batch * sG * sizeof(float), hipMemcpyDeviceToDevice, st));
