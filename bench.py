@@ -334,20 +334,6 @@ def main():
         barrier()
         prof_single = _lib.profile_summary()
         _lib.profile_enable(False)
-    # The launches of the timed configuration carry one to four problems (same-input linears fitted in lockstep); the
-    # counter replay behind `traffic` issues problems one by one.  One more single-stream step with the lockstep groups
-    # off counts the problems per family, which turns the measured bytes per problem into bytes per launch.
-    prof_problems = None
-    if world == 1:
-        import slim_amd.prune as _P
-        grouped = _P.GROUP_FITS
-        _P.GROUP_FITS = False
-        _lib.profile_enable(True)
-        step(1) if mode == "layers" else step()
-        barrier()
-        prof_problems = _lib.profile_summary()
-        _lib.profile_enable(False)
-        _P.GROUP_FITS = grouped
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = block_bytes * args.steps / dt / 1e9
@@ -375,11 +361,9 @@ def main():
         def roof(dom):
             if dom is None:
                 return None
-            per_problem = measured_traffic(dom["name"])
-            problems = (prof_problems or {}).get(dom["name"], {}).get("count", 0) / dom["count"] if dom["count"] else 0.0
-            extra = {"traffic": per_problem * problems if (per_problem and problems) else None,
-                     "traffic_per_problem": per_problem, "problems_per_launch": round(problems, 3),
-                     "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+            # HBM bytes per launch from the counter passes over this same program on a single stream (the launches there carry
+            # the same lockstep groups as here), beside the algorithmic bytes of the same launches
+            extra = {"traffic": measured_traffic(dom["name"]), "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                      "avg_launch_us": dom["avg_us"], "launches": dom["count"],
                      "measured": "one extra untimed step on a single stream"}
             if dom["name"].startswith("gemm"):
