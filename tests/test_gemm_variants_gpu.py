@@ -60,3 +60,24 @@ def test_symmetric_splitk_equals_full_product(n, kd, splits):
     torch.cuda.synchronize()
     assert torch.equal(sym32, full32) and torch.equal(sym16, full16)
     assert torch.equal(sym32, sym32.t())
+
+
+@pytest.mark.parametrize("M,N,Kd", [(576, 4096, 4096), (576, 2056, 1600), (1152, 2048, 2048), (288, 1664, 1544), (320, 2048, 2048)])
+def test_tall_tile_equals_square_tile(M, N, Kd):
+    """The 288 x 128 tile (512 threads) the launcher picks for the (l x Dm) products of the fit (bf16 C and C^T, M the subspace
+    dimension) against the 128 x 128 tile forced on the same operands: the same fp32 sums in the same order, so identical
+    outputs.  (320 rows: the tall tile would pad more than the square one and is not picked; the case keeps the rule honest.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slim_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = torch.randn(M, Kd, device="cuda", generator=g).to(torch.bfloat16)
+    Bt = torch.randn(N, Kd, device="cuda", generator=g).to(torch.bfloat16)
+    _, C16, Ct = ops.gemm_nt(A, Bt, out_bf16=True, out_t=True)                   # launcher's choice
+    _lib.query("slim_gemm_set_tile", 0)
+    _, R16, Rt = ops.gemm_nt(A, Bt, out_bf16=True, out_t=True)
+    torch.cuda.synchronize()
+    assert torch.equal(C16, R16) and torch.equal(Ct, Rt)
+    assert torch.equal(Ct, C16.t())
+    ref = A.double() @ Bt.double().t()
+    assert (C16.double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
