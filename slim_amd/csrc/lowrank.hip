@@ -1256,7 +1256,9 @@ extern "C" int slim_outlier_basis(const void* Et, int64_t N, const int32_t* cols
     float* T = (float*)((char*)workspace + al256((int64_t)tp * tp * 8));
     outlier_gram_kernel<<<dim3((unsigned)tp, (unsigned)tp), 256, 0, st>>>((const bf16_t*)Et, N, cols, t, tp, G);
     SLIM_LAUNCH_CHECK();
-    outlier_basis_kernel<<<1, 64, (size_t)(2 * t * t + 2 * t) * sizeof(double), st>>>(G, t, tp, T);
+    const size_t basis_lds = (size_t)(2 * t * t + 2 * t) * sizeof(double);       // 65 KiB at t = 64: above the default limit
+    SLIM_HIP(slim_allow_dynamic_lds((const void*)outlier_basis_kernel, (int)basis_lds));
+    outlier_basis_kernel<<<1, 64, basis_lds, st>>>(G, t, tp, T);
     SLIM_LAUNCH_CHECK();
     const size_t q_lds = ((size_t)t * 256 + (size_t)tp * tp) * sizeof(float);
     SLIM_HIP(slim_allow_dynamic_lds((const void*)outlier_q_kernel, (int)q_lds));

@@ -90,3 +90,43 @@ def test_fused_prepare_with_given_mask_and_no_quantiser():
     torch.cuda.synchronize()
     assert torch.equal(got.W_mask, mask)
     assert torch.equal(got.E, ref.E) and torch.equal(got.Et, ref.Et)
+
+
+@pytest.mark.parametrize("N,t,tp", [(768, 1, 8), (1024, 13, 16), (4096, 64, 64), (520, 40, 40)])
+def test_outlier_basis_is_orthonormal_and_spans_the_columns(N, t, tp):
+    """slim_outlier_basis / slim_outlier_project on their own, up to the 64 columns the driver may split off: an orthonormal
+    basis (to bf16 rounding) of the listed columns whatever their scales, zero padding columns, and the projection of every
+    column of E on it; a repeated column drops out instead of poisoning the basis."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slim_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(N + t)
+    K = 256
+    E = torch.randn(N, K, device="cuda", generator=g)
+    cols = torch.randperm(K, device="cuda", generator=g)[:tp].to(torch.int32)
+    E[:, cols[:t].long()] *= torch.logspace(0, 3, t, device="cuda")            # scales three orders of magnitude apart
+    E = E.to(torch.bfloat16)
+    Et = E.t().contiguous()
+    UO, UOt = ops.outlier_basis(Et, cols, t)
+    torch.cuda.synchronize()
+    assert torch.equal(UOt, UO.t().contiguous())
+    assert float(UO[:, t:].abs().max()) == 0.0 if tp > t else True
+    G = UO[:, :t].float().t() @ UO[:, :t].float()
+    assert float((G - torch.eye(t, device="cuda")).abs().max()) < 3e-2
+    EO = E.float()[:, cols[:t].long()]
+    proj = UO.float() @ (UO.float().t() @ EO)
+    assert float(((proj - EO).norm(dim=0) / EO.norm(dim=0)).max()) < 3e-2
+    Ct = ops.outlier_project(Et, UOt)
+    ref = (Et.float() @ UO.float())
+    assert float((Ct.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max()) + 1e-6
+    if t >= 2:
+        # the second listed column equal to the first: its direction is dropped, the others stay orthonormal
+        cols2 = cols.clone()
+        cols2[1] = cols2[0]
+        UO2, _ = ops.outlier_basis(Et, cols2, t)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(UO2.float()).all())
+        assert float(UO2[:, 1].abs().max()) == 0.0
+        keep = [0] + list(range(2, t))
+        G2 = UO2[:, keep].float().t() @ UO2[:, keep].float()
+        assert float((G2 - torch.eye(len(keep), device="cuda")).abs().max()) < 3e-2
