@@ -167,6 +167,10 @@ int slim_error_matrix(const void* W_bf16, const uint8_t* mask, const float* s, c
 int slim_error_matrix_deq(const void* W_bf16, const void* Wdeq_bf16, const uint8_t* mask, const float* s, int64_t N,
                           int64_t K, float* E_f32, void* E_bf16, void* stream);
 
+/* slim_error_matrix (per-tensor quantiser or none, bf16 output) and the transpose of its result in one pass: E [N, K] and
+ * Et [K, N]; N and K multiples of 8. */
+int slim_error_matrix_t(const void* W_bf16, const uint8_t* mask, const float* s, const float* sf, int num_bits, int64_t N,
+                        int64_t K, void* E_bf16, void* Et_bf16, void* stream);
 int slim_transpose_bf16(const void* in, int64_t R, int64_t C, void* out, void* stream);
 
 /* C[M, N] = alpha * A[M, Kd] * Bt[N, Kd]^T + beta * C_f32, bf16 operands (reduction dimension
@@ -363,6 +367,10 @@ int slim_outlier_basis(const void* Et_bf16, int64_t N, const int32_t* cols, int 
                        int64_t workspace_bytes, void* stream);
 /* Ct [K, tp] = bf16(Et UOt^T) (fp32 accumulation): every column of E projected on the basis of slim_outlier_basis. */
 int slim_outlier_project(const void* Et_bf16, const void* UOt, int64_t K, int64_t N, int tp, void* Ct, void* stream);
+/* E2 [N, K] = bf16(E - bf16(UO Ct^T)) and E2t = its transpose, in one pass (the rounding points of slim_lowrank_residual; the
+ * fp32 sums over the tp <= 64 columns run in column order). */
+int slim_deflate_apply(const void* E_bf16, const void* UO, const void* Ct, int64_t N, int64_t K, int tp, void* E2_bf16,
+                       void* E2t_bf16, void* stream);
 int64_t slim_lora_prepare_workspace_bytes(int64_t N, int64_t K, int tp);
 int slim_lora_prepare(const void* W_bf16, const float* scaler_row, int64_t N, int64_t K, int prune_n, int prune_m, uint8_t* mask,
                       int quant_mode, int num_bits, int scale_error, float* s_out, float* sf_out, void* E_bf16, void* Et_bf16,

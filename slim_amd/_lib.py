@@ -78,6 +78,8 @@ PROTOTYPES = {
     "slim_gramfit_factors": (i32, [i32, vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, vp]),
     "slim_lora_assemble": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "slim_outlier_project": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "slim_error_matrix_t": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
+    "slim_deflate_apply": (i32, [vp, vp, vp, i64, i64, i32, vp, vp, vp]),
     "slim_outlier_basis_workspace_bytes": (i64, [i32]),
     "slim_outlier_basis": (i32, [vp, i64, vp, i32, i32, vp, vp, vp, i64, vp]),
     "slim_lora_prepare_workspace_bytes": (i64, [i64, i64, i32]),

@@ -1239,6 +1239,72 @@ extern "C" int slim_outlier_project(const void* Et, const void* UOt, int64_t K, 
     return SLIM_OK;
 }
 
+// E2 [N, K] = bf16(E - bf16(UO Ct^T)) and its transpose in one pass (UO [N, tp], Ct [K, tp], tp <= 64): the subtraction of
+// the exact part of the split-off columns.  With so short a reduction the product is element-wise work: 64 x 64 tiles, the
+// two operand tiles in LDS, fp32 sums in column order, the rounding points of slim_lowrank_residual.
+__global__ __launch_bounds__(256) void deflate_apply_kernel(const bf16_t* __restrict__ E, const bf16_t* __restrict__ UO,
+                                                            const bf16_t* __restrict__ Ct, int64_t N, int64_t K, int tp,
+                                                            bf16_t* __restrict__ E2, bf16_t* __restrict__ E2t) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* us = dsm;                      // [64][tp + 1]
+    float* cs = dsm + 64 * (tp + 1);      // [64][tp + 1]
+    bf16_t* tile = (bf16_t*)(dsm + 2 * 64 * (tp + 1));      // [64][72]
+    const int64_t n0 = (int64_t)blockIdx.y * 64, k0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x, c = (t & 7) * 8;
+    for (int idx = t; idx < 64 * tp; idx += 256) {
+        const int r = idx / tp, j = idx - r * tp;
+        us[r * (tp + 1) + j] = n0 + r < N ? bf16_to_f32(UO[(n0 + r) * tp + j]) : 0.f;
+        cs[r * (tp + 1) + j] = k0 + r < K ? bf16_to_f32(Ct[(k0 + r) * tp + j]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = (t >> 3) + 32 * pass;
+        const int64_t row = n0 + r, col = k0 + c;
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < N && col < K) {
+            const u16x8 e = *(const u16x8*)(E + row * K + col);
+            float lr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lr[u] = 0.f;
+            for (int j = 0; j < tp; ++j) {
+                const float uj = us[r * (tp + 1) + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) lr[u] += uj * cs[(c + u) * (tp + 1) + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = f32_to_bf16(bf16_to_f32(e[u]) - round_bf16(lr[u]));
+            *(u16x8*)(E2 + row * K + col) = o;
+        }
+        *(u16x8*)(tile + r * 72 + c) = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kc = (t >> 3) + 32 * pass;
+        const int64_t col = k0 + kc, row = n0 + c;
+        if (col >= K || row >= N) continue;
+        u16x8 o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = tile[(c + u) * 72 + kc];
+        *(u16x8*)(E2t + col * N + row) = o;
+    }
+}
+
+extern "C" int slim_deflate_apply(const void* E, const void* UO, const void* Ct, int64_t N, int64_t K, int tp, void* E2, void* E2t,
+                                  void* stream) {
+    SLIM_REQUIRE(E && UO && Ct && E2 && E2t && N > 0 && K > 0, "slim_deflate_apply: bad arguments");
+    SLIM_REQUIRE(N % 8 == 0 && K % 8 == 0 && tp > 0 && tp <= 64, "slim_deflate_apply: N, K multiples of 8 and tp in [1, 64]");
+    SLIM_REQUIRE(ceil_div64(N, 64) <= 65535, "slim_deflate_apply: too many rows");
+    const size_t lds = (size_t)2 * 64 * (tp + 1) * sizeof(float) + (size_t)64 * 72 * sizeof(bf16_t);
+    SLIM_PROF("deflate_apply", stream, 6.0 * N * K);
+    dim3 grid((unsigned)ceil_div64(K, 64), (unsigned)ceil_div64(N, 64));
+    deflate_apply_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)E, (const bf16_t*)UO, (const bf16_t*)Ct, N, K, tp,
+                                                                   (bf16_t*)E2, (bf16_t*)E2t);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 static inline int64_t prepare_search_bins(int64_t numel) { return numel / 1000 < 512 ? 512 : (numel / 1000 > 20000 ? 20000 : numel / 1000); }
 
 extern "C" int64_t slim_outlier_basis_workspace_bytes(int tp) {
@@ -1303,13 +1369,11 @@ extern "C" int slim_lora_prepare(const void* W, const float* scaler_row, int64_t
         if (quant_mode == 1) CHK(slim_quant_search(hist, (int)bins, num_bits, alpha, nullptr, sf_out, search_ws, search_bytes, stream));
         else CHK(slim_absmax_scale(hist, num_bits, alpha, sf_out, stream));
     }
-    CHK(slim_error_matrix(W, mask, scale_error ? s_out : nullptr, quant_mode ? sf_out : nullptr, num_bits, N, K, nullptr, E, stream));
-    CHK(slim_transpose_bf16(E, N, K, Et, stream));
+    CHK(slim_error_matrix_t(W, mask, scale_error ? s_out : nullptr, quant_mode ? sf_out : nullptr, num_bits, N, K, E, Et, stream));
     if (t == 0) return SLIM_OK;
     CHK(slim_outlier_basis(Et, N, outlier_idx, t, tp, UO, UOt, basis_ws, slim_outlier_basis_workspace_bytes(tp), stream));
     CHK(slim_outlier_project(Et, UOt, K, N, tp, Ct, stream));
-    CHK(slim_lowrank_residual(UO, Ct, (int)N, (int)K, tp, E, nullptr, E2, nullptr, stream));
-    CHK(slim_transpose_bf16(E2, N, K, E2t, stream));
+    CHK(slim_deflate_apply(E, UO, Ct, N, K, tp, E2, E2t, stream));
     return SLIM_OK;
 }
 

@@ -573,6 +573,81 @@ extern "C" int slim_error_matrix(const void* W, const uint8_t* mask, const float
     return SLIM_OK;
 }
 
+// The same matrix (per-tensor quantiser or none) written as E [N, K] and E^T [K, N] in one pass: 64 x 64 tiles, rows of E
+// straight from the registers, the transposed tile through LDS (the separate transpose read E a second time).  The element
+// arithmetic is error_matrix_kernel's.
+__global__ __launch_bounds__(256) void error_matrix_t_kernel(const bf16_t* __restrict__ w, const uint8_t* __restrict__ mask,
+                                                             const float* __restrict__ s, const float* __restrict__ sf_p,
+                                                             int num_bits, int64_t N, int64_t K, bf16_t* __restrict__ e16,
+                                                             bf16_t* __restrict__ et16) {
+    __shared__ bf16_t tile[64][72];      // row stride 144 bytes: 16-byte rows for the vector stores, odd multiple of 16 bytes
+    const float sf = sf_p ? sf_p[0] : 0.f;
+    const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
+    const int64_t n0 = (int64_t)blockIdx.y * 64, k0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x, c = (t & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = (t >> 3) + 32 * pass;
+        const int64_t row = n0 + r, col = k0 + c;
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < N && col < K) {
+            const int64_t off = row * K + col;
+            const u16x8 x = *(const u16x8*)(w + off);
+            const uint2 mk = *(const uint2*)(mask + off);
+            float sv[8];
+            if (s) {
+                const f32x4 a = *(const f32x4*)(s + col), b = *(const f32x4*)(s + col + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sv[j] = a[j];
+                    sv[4 + j] = b[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sv[j] = 1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float wf = bf16_to_f32(x[j]);
+                const float metric = wf * sv[j];
+                const bool pruned = ((j < 4 ? mk.x >> (8 * j) : mk.y >> (8 * (j - 4))) & 0xffu) != 0;
+                float nw;
+                if (pruned) nw = 0.f;
+                else if (sf_p) nw = (quant_code(x[j], sf, qmin, qmax) / sf) * sv[j];
+                else nw = metric;
+                o[j] = f32_to_bf16(metric - nw);
+            }
+            *(u16x8*)(e16 + off) = o;
+        }
+        *(u16x8*)&tile[r][c] = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kc = (t >> 3) + 32 * pass;          // column of the tile = row of E^T
+        const int64_t col = k0 + kc, row = n0 + c;
+        if (col >= K || row >= N) continue;
+        u16x8 o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = tile[c + u][kc];
+        *(u16x8*)(et16 + col * N + row) = o;
+    }
+}
+
+extern "C" int slim_error_matrix_t(const void* W, const uint8_t* mask, const float* s, const float* sf, int num_bits, int64_t N,
+                                   int64_t K, void* E_bf16, void* Et_bf16, void* stream) {
+    SLIM_REQUIRE(W && mask && E_bf16 && Et_bf16 && N > 0 && K > 0, "slim_error_matrix_t: bad arguments");
+    SLIM_REQUIRE(K % 8 == 0 && N % 8 == 0, "slim_error_matrix_t: N and K must be multiples of 8");
+    SLIM_REQUIRE(!sf || (num_bits >= 2 && num_bits <= 8), "slim_error_matrix_t: num_bits must be in [2, 8]");
+    SLIM_REQUIRE(ceil_div64(N, 64) <= 65535, "slim_error_matrix_t: too many rows");
+    SLIM_PROF("error_matrix", stream, 7.0 * N * K);
+    dim3 grid((unsigned)ceil_div64(K, 64), (unsigned)ceil_div64(N, 64));
+    error_matrix_t_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K, (bf16_t*)E_bf16,
+                                                                 (bf16_t*)Et_bf16);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 // Same with the dequantised weight given as a tensor (any quantiser, e.g. the tiled group quantiser whose
 // dequantised values are bf16): E = W * s - mask0(Wdeq * s).
 extern "C" int slim_error_matrix_deq(const void* W, const void* Wdeq, const uint8_t* mask, const float* s, int64_t N,

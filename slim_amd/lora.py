@@ -103,8 +103,8 @@ def deflate_outliers(E, Et, outliers, out=None):
     UO, UOt = ops.outlier_basis(Et, cols, t)
     info_o = torch.zeros(64, dtype=torch.int32, device=E.device)
     Ct = ops.outlier_project(Et, UOt)
-    E2 = ops.lowrank_residual(UO, Ct, E, None, out=out)
-    return E2, UO, Ct, info_o
+    E2, E2t = ops.deflate_apply(E, UO, Ct, out=out)
+    return E2, UO, Ct, info_o, E2t
 
 
 def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, info_o=None):
@@ -140,8 +140,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
         raise NotImplementedError(f"rank {rank} of a {N}x{K} layer is not reachable with 8-aligned subspaces")
     UO = Ct = info_o = None
     if t:
-        E, UO, Ct, info_o = deflate_outliers(E, Et, outliers)
-        Et = ops.transpose(E)
+        E, UO, Ct, info_o, Et = deflate_outliers(E, Et, outliers)
     fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
                           ns_steps=fit_ns_steps(spread, hint), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
                           sketch_split=FIT_SKETCH_SPLIT)
@@ -184,8 +183,8 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
 
 def deflated_pair(E, Et, outliers):
     """(E', E'^T, Q_O, C^T, status words) of deflate_outliers: what the fit of a layer with outlier columns starts from."""
-    E2, UO, Ct, info_o = deflate_outliers(E, Et, outliers)
-    return E2, ops.transpose(E2), UO, Ct, info_o
+    E2, UO, Ct, info_o, E2t = deflate_outliers(E, Et, outliers)
+    return E2, E2t, UO, Ct, info_o
 
 
 def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None):

@@ -648,6 +648,16 @@ def outlier_project(Et, UOt):
     return Ct
 
 
+def deflate_apply(E, UO, Ct, out=None):
+    """(E2, E2t) = (bf16(E - bf16(UO @ Ct.T)), its transpose) in one pass (slim_deflate_apply)."""
+    E, UO, Ct = _chk(E, BF16, "E"), _chk(UO, BF16, "UO"), _chk(Ct, BF16, "Ct")
+    N, K = E.shape
+    E2 = _out_or_new(out, (N, K), E.device, "deflate_apply")
+    E2t = torch.empty(K, N, dtype=BF16, device=E.device)
+    _lib.call("slim_deflate_apply", _p(E), _p(UO), _p(Ct), N, K, UO.shape[1], _p(E2), _p(E2t), _stream())
+    return E2, E2t
+
+
 def lora_assemble(UO, Ct, s, fitU, fitL, t, rank, r8):
     """(U [N, r8], Ut [r8, N], L [K, r8]) of slim_lora_assemble: the exact part of the split-off outlier columns in front of
     the randomized fit's factors."""

@@ -18,7 +18,7 @@ for N, K, rank in shapes:
     rf, over, l, t = LORA.fit_plan(N, K, rank, outl)
     Et = ops.transpose(E)
     if t:
-        E2, UO, Ct, _ = LORA.deflate_outliers(E, Et, outl)
+        E2, UO, Ct, _, _ = LORA.deflate_outliers(E, Et, outl)
         Et2 = ops.transpose(E2)
     else:
         E2, Et2 = E, Et
