@@ -47,6 +47,7 @@ PROTOTYPES = {
     "slim_lora_prune_workspace_bytes": (i64, [i64, i64, i64]),
     "slim_lora_prune_optimize": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, f32, f32, vp, vp, i64, vp]),
     "slim_gemm_set_tile": (None, [i32]),
+    "slim_linear24_set_wide": (None, [i32]),
     "slim_gemm_set_family_tile": (None, [i32, i32]),
     "slim_gemm_set_trace": (None, [vp, i32]),
     "slim_eigh_workspace_bytes": (i64, [i32]),

@@ -28,6 +28,8 @@
 // 4096 x 4096 layer at batch 1 still fills 256 CUs.
 #include "common.hpp"
 #include "../../include/slim_hip.h"
+#include "gemm.hpp"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(16))) __bf16 bf16x16;
 
@@ -265,7 +267,7 @@ __device__ __forceinline__ void store_packed_tile(bf16_t* lds, uint2 v, uint32_t
 }
 
 template <int WAVES_M, int FR_M>
-__global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
+__global__ __launch_bounds__(256, (WAVES_M * FR_M <= 8 ? 2 : 1)) void linear24_kernel(FwdArgs g) {
     constexpr int TBM = WAVES_M * FR_M * 16;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int FR_N = FBN / (WAVES_N * 16);
@@ -505,6 +507,327 @@ __global__ __launch_bounds__(256) void linear24_kernel(FwdArgs g) {
                 for (int r = 0; r < 4; ++r) dst[r] = o[r];
             }
         }
+}
+
+// Main product alone on a wide tile, for batches of hundreds of rows and more.  The 128 x 128 tile above is bound by the
+// LDS, not by the matrix pipe: per K-step it expands the packed tile through randomly addressed table reads (bank
+// conflicts), writes it to LDS and reads every fragment back, for only 16 sparse instructions per wave.  Here a workgroup
+// of 8 waves owns 128 activation rows x 512 weight rows, and wave w owns weight rows 64 w .. 64 w + 63 of the panel against
+// ALL 128 activation rows:
+//   * the weight never passes through LDS: a lane loads the packed bytes of its own operand slots straight from memory
+//     (per instruction 4 code bytes + 16 position bits; the 16 lanes of a row group read 2 x 128 contiguous bytes) and turns
+//     them into levels in registers;
+//   * the code-byte -> two-levels table is replicated once per LDS bank (entry e of lane l at dword 32 e + (l & 31), 32 KiB):
+//     every lane reads its own bank, so a lookup costs the conflict-free 2 cycles instead of ~7;
+//   * only the activation tile is staged in LDS (two buffers, one barrier per K-step), read by every wave as 8 row blocks
+//     for 8 x 4 sparse instructions, two row blocks at a time so that the reads of the next pair overlap the instructions
+//     of the current one.
+// Per K-step and CU: ~1000 LDS cycles against ~1100 matrix cycles (two waves per SIMD), where the 128 x 128 tile needs
+// ~2500 for a quarter of the products.  No split reduction; the second product follows in the same launch (below).
+#define WIDE_TBM 128
+#define WIDE_TBN 512
+#define WIDE_NT 512
+// LDS row strides (bf16 elements) of the activation tiles: 64 + 16 and 32 + 16.  With these the 16 lanes that a ds_read_b128
+// serves per cycle (rows r, r + 12 .. and the neighbouring 8-channel piece of rows r + 4 ..) fall on 16 different groups of four
+// banks; 64 + 8 and 32 + 8 put two of them on the same banks (38 % of the LDS cycles were conflict cycles).
+#define WSTRIDE 80
+#define WSTRIDE2 48
+__global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
+    constexpr int NT = WIDE_NT, TBM = WIDE_TBM, TBN = WIDE_TBN, FR_M = TBM / 16, FR_N = 4;
+    constexpr int NA = TBM * 8 / NT;                       // 16-byte pieces of the activation tile per thread
+    constexpr int XBYTES = TBM * WSTRIDE * 2;
+    extern __shared__ __attribute__((aligned(16))) char wsmem[];
+    uint32_t* lut = (uint32_t*)(wsmem + 2 * XBYTES);       // [256][32]
+
+    // tile order as in the kernel above: an XCD's share of the workgroups is contiguous, and inside it consecutive
+    // workgroups cycle over a group of 8 weight panels before they move to the next activation tile
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+    const int tiles_m = (g.M + TBM - 1) / TBM, tiles_n = (g.N + TBN - 1) / TBN;
+    const int grp = wgid / (8 * tiles_m), in_grp = wgid % (8 * tiles_m);
+    const int gn = min(8, tiles_n - grp * 8);
+    const int tn = grp * 8 + in_grp % gn, tm = in_grp / gn;
+    const int row0 = tm * TBM, col0 = tn * TBN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    {
+        const float sf = *g.sf;
+#pragma unroll
+        for (int i = 0; i < 256 * 32 / NT; ++i) {
+            const int q = t + NT * i, e = q >> 5;
+            const int c0 = ((int)((uint32_t)e << 28)) >> 28, c1 = ((int)((uint32_t)e << 24)) >> 28;
+            lut[q] = (uint32_t)f32_to_bf16((float)c0 / sf) | ((uint32_t)f32_to_bf16((float)c1 / sf) << 16);
+        }
+    }
+    const uint32_t* my_lut = lut + (lane & 31);
+
+    f32x4 acc[FR_M][FR_N];
+#pragma unroll
+    for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Per K-step a thread brings in NA pieces of the activation tile (to LDS) and, for each of its FR_N weight row blocks, the
+    // 4 code bytes and 16 position bits of its operand slots: lane (n = fr, kq = fq) holds the kept values of dense channels
+    // 16 kq .. 16 kq + 15 of row n, i.e. bytes 4 (kq & 1) .. + 3 of the codes and half-word kq & 1 of the positions of the packed
+    // unit (row, 32-channel half kq >> 1).  The last panel of a weight whose row count is not a multiple of TBN reads the
+    // last 128-row tile again (never stored).
+    struct Regs {
+        u16x8 ra[NA];
+        uint32_t code[FR_N];
+        uint32_t pos[FR_N];
+    };
+    const int64_t ktiles = g.K / FBK;
+    const bf16_t* xp[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = t + NT * i;
+        int row = row0 + (c >> 3);
+        row = row < g.M ? row : g.M - 1;
+        xp[i] = g.x + (int64_t)row * g.ldx + (c & 7) * 8;
+    }
+    const int tn128 = min(col0 / 128 + (wave >> 1), g.N / 128 - 1);
+    const int64_t unit0 = ((int64_t)tn128 * ktiles * 2 + (fq >> 1)) * 128 + (wave & 1) * 64 + fr;
+    const uint8_t* cp = g.vals + unit0 * 8 + (fq & 1) * 4;
+    const uint8_t* mp = g.meta + unit0 * 4 + (fq & 1) * 2;
+    auto load = [&](Regs& r, int kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) r.ra[i] = *(const u16x8*)(xp[i] + (int64_t)kt * FBK);
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) {
+            r.code[j] = *(const uint32_t*)(cp + (int64_t)kt * 2048 + j * 128);
+            r.pos[j] = *(const unsigned short*)(mp + (int64_t)kt * 1024 + j * 64);
+        }
+    };
+    auto store = [&](const Regs& r, int buf) {
+        char* xb = wsmem + buf * XBYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = t + NT * i;
+            *(u16x8*)(xb + ((c >> 3) * WSTRIDE + (c & 7) * 8) * 2) = r.ra[i];
+        }
+    };
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    // One K-step: the codes of register set `r` become levels, the set is reloaded for step kt_next at once (its activation
+    // pieces went to LDS a step ago), then the products from LDS buffer `buf`.  Operand layout of the sparse instruction: see
+    // mma_sparse in the kernel above.
+    auto step = [&](Regs& r, int buf, int kt_next) {
+        const bf16_t* a_base = (const bf16_t*)(wsmem + buf * XBYTES) + fr * WSTRIDE + fq * 8;
+        auto read_x = [&](int i) {
+            const bf16x8 lo = *(const bf16x8*)(a_base + i * 16 * WSTRIDE), hi = *(const bf16x8*)(a_base + i * 16 * WSTRIDE + 32);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        };
+        bf16x8 wf[FR_N];
+        int idx[FR_N];
+        bf16x16 xa[2], xb[2];
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) {
+            const uint32_t c = r.code[j];
+            const u32x4 v = {my_lut[(c & 0xffu) * 32], my_lut[((c >> 8) & 0xffu) * 32], my_lut[((c >> 16) & 0xffu) * 32], my_lut[(c >> 24) * 32]};
+            wf[j] = __builtin_bit_cast(bf16x8, v);
+            idx[j] = (int)r.pos[j];
+        }
+        xa[0] = read_x(0);
+        xa[1] = read_x(1);
+        load(r, kt_next);
+#pragma unroll
+        for (int p = 0; p < FR_M / 2; p += 2) {
+            xb[0] = read_x(2 * p + 2);
+            xb[1] = read_x(2 * p + 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < FR_N; ++j)
+                    acc[2 * p + ii][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xa[ii], acc[2 * p + ii][j], idx[j], 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * p + 4 < FR_M) {
+                xa[0] = read_x(2 * p + 4);
+                xa[1] = read_x(2 * p + 5);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < FR_N; ++j)
+                    acc[2 * p + 2 + ii][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xb[ii], acc[2 * p + 2 + ii][j], idx[j], 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // K-steps two ahead in registers, the activation tile one ahead in LDS; every load and store unconditional (see
+    // `pipeline` above: past the end the last step is fetched again and never multiplied)
+    const int nk = (int)ktiles, last = nk - 1;
+    Regs regs[2];
+    load(regs[0], 0);
+    load(regs[1], min(1, last));
+    store(regs[0], 0);
+    __syncthreads();                  // also publishes the table
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(regs[0], 0, min(kt + 2, last));
+        store(regs[1], 1);
+        __syncthreads();
+        if (kt + 1 < nk) step(regs[1], 1, min(kt + 3, last));
+        store(regs[0], 0);
+        __syncthreads();
+    }
+
+    // y = bf16(acc + bias).  With a second product this is the first term of the sum: it is written now and read back by the
+    // same lanes after the second product (from L2 or Infinity Cache), which keeps the accumulators free for it.  (Parking it
+    // in LDS instead -- 128 KiB -- is possible on paper; the compiler then spills ~250 registers in the first product's loop.)
+    constexpr int XBYTES2 = TBM * WSTRIDE2 * 2;            // second product: 32 channels per row and step
+    const bool wide = (g.ldy & 3) == 0 && ((uintptr_t)g.y & 7) == 0;
+    // (all loads of an epilogue are issued before the first value is used, from clamped addresses and without branches: a
+    // load inside a guarded block is waited for on the spot, 32 memory round trips in a row per workgroup)
+    auto write_out = [&](bool add_to_y) {
+        float bv[FR_N][4];
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) {
+            const int n = min(col0 + wave * 64 + j * 16 + fq * 4, g.N - 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[j][r] = (!add_to_y && g.bias) ? bf16_to_f32(g.bias[n + r]) : 0.f;
+        }
+        uint2 prev[FR_M][FR_N];
+        if (add_to_y) {
+#pragma unroll
+            for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+                for (int j = 0; j < FR_N; ++j) {
+                    const int m = min(row0 + i * 16 + fr, g.M - 1);
+                    const int n = min(col0 + wave * 64 + j * 16 + fq * 4, g.N - 4);
+                    const bf16_t* src = g.y + (int64_t)m * g.ldy + n;
+                    if (wide) prev[i][j] = *(const uint2*)src;
+                    else prev[i][j] = make_uint2((uint32_t)src[0] | ((uint32_t)src[1] << 16), (uint32_t)src[2] | ((uint32_t)src[3] << 16));
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+            for (int j = 0; j < FR_N; ++j) {
+                const int m = row0 + i * 16 + fr;
+                const int n = col0 + wave * 64 + j * 16 + fq * 4;
+                bf16_t o[4];
+                if (add_to_y) {
+                    const uint2 v = prev[i][j];
+                    const bf16_t h[4] = {(bf16_t)(v.x & 0xffffu), (bf16_t)(v.x >> 16), (bf16_t)(v.y & 0xffffu), (bf16_t)(v.y >> 16)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(bf16_to_f32(h[r]) + round_bf16(acc[i][j][r]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(acc[i][j][r] + bv[j][r]);
+                }
+                if (m >= g.M || n >= g.N) continue;
+                bf16_t* dst = g.y + (int64_t)m * g.ldy + n;
+                if (wide) *(uint2*)dst = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r] = o[r];
+                }
+            }
+    };
+    write_out(false);
+    if (!g.Bt) return;
+
+    // Second product a [M, Ka] * Bt[N, Ka]^T (dense bf16 on both sides, the adapter term), K-steps of 32: the rows of Bt are
+    // wave-private like the packed rows, so a lane loads its operand slots (8 consecutive reduction channels of one row)
+    // straight from memory; the tile of `a` goes through LDS (one 16-byte piece per thread and step).  Pieces at or past Ka
+    // (a multiple of 8) read as zero; `a` has zero columns up to the next multiple of 128.
+#pragma unroll
+    for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    struct Regs2 {
+        u16x8 ra;
+        u16x8 b[FR_N];
+    };
+    // (the thread index passes through an empty asm statement so that the addresses of this phase are computed here and do not
+    // occupy registers during the first product, whose loop has none to spare)
+    int t2 = t;
+    asm volatile("" : "+v"(t2));
+    const int fr2 = t2 & 15, fq2 = (t2 >> 4) & 3, wave2 = t2 >> 6;
+    int arow = row0 + (t2 >> 2);
+    arow = arow < g.M ? arow : g.M - 1;
+    const bf16_t* ap = g.a + (int64_t)arow * g.lda + (t2 & 3) * 8;
+    const bf16_t* bp[FR_N];
+#pragma unroll
+    for (int j = 0; j < FR_N; ++j) {
+        int n = col0 + wave2 * 64 + j * 16 + fr2;
+        n = n < g.N ? n : g.N - 1;
+        bp[j] = g.Bt + (int64_t)n * g.ldb + fq2 * 8;
+    }
+    auto load2 = [&](Regs2& r, int kt) {
+        // (a piece past Ka is fetched from the start of the row and zeroed where it is used: zeroing it here would make the
+        // loop wait for the load at once)
+        r.ra = *(const u16x8*)(ap + kt * 32);
+        const int k = kt * 32 + fq2 * 8 < g.Ka ? kt * 32 : 0;
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) r.b[j] = *(const u16x8*)(bp[j] + k);
+    };
+    auto store2 = [&](const Regs2& r, int buf) {
+        *(u16x8*)(wsmem + buf * XBYTES2 + ((t >> 2) * WSTRIDE2 + (t & 3) * 8) * 2) = r.ra;
+    };
+    auto step2 = [&](Regs2& r, int buf, int kt, int kt_next) {
+        const bf16_t* a_base = (const bf16_t*)(wsmem + buf * XBYTES2) + fr * WSTRIDE2 + fq * 8;
+        bf16x8 wf[FR_N], xa[2], xb[2];
+        const bool in = kt * 32 + fq2 * 8 < g.Ka;
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) wf[j] = __builtin_bit_cast(bf16x8, in ? r.b[j] : u16x8{0, 0, 0, 0, 0, 0, 0, 0});
+        xa[0] = *(const bf16x8*)(a_base);
+        xa[1] = *(const bf16x8*)(a_base + 16 * WSTRIDE2);
+        load2(r, kt_next);
+#pragma unroll
+        for (int p = 0; p < FR_M / 2; p += 2) {
+            xb[0] = *(const bf16x8*)(a_base + (2 * p + 2) * 16 * WSTRIDE2);
+            xb[1] = *(const bf16x8*)(a_base + (2 * p + 3) * 16 * WSTRIDE2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < FR_N; ++j)
+                    acc[2 * p + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xa[ii], acc[2 * p + ii][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * p + 4 < FR_M) {
+                xa[0] = *(const bf16x8*)(a_base + (2 * p + 4) * 16 * WSTRIDE2);
+                xa[1] = *(const bf16x8*)(a_base + (2 * p + 5) * 16 * WSTRIDE2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < FR_N; ++j)
+                    acc[2 * p + 2 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xb[ii], acc[2 * p + 2 + ii][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int nk2 = (g.Ka + 31) / 32, last2 = nk2 - 1;
+    Regs2 regs2[2];
+    load2(regs2[0], 0);
+    load2(regs2[1], min(1, last2));
+    store2(regs2[0], 0);              // (the loop above ended with a barrier: the first product's buffers are free)
+    __syncthreads();
+    for (int kt = 0; kt < nk2; kt += 2) {
+        step2(regs2[0], 0, kt, min(kt + 2, last2));
+        store2(regs2[1], 1);
+        __syncthreads();
+        if (kt + 1 < nk2) step2(regs2[1], 1, kt + 1, min(kt + 3, last2));
+        store2(regs2[0], 0);
+        __syncthreads();
+    }
+    write_out(true);
+}
+
+static int launch_linear24_wide(const FwdArgs& g, hipStream_t st) {
+    const int lds = 2 * WIDE_TBM * WSTRIDE * 2 + 256 * 32 * 4;      // two activation buffers + the replicated table
+    SLIM_HIP(slim_allow_dynamic_lds((const void*)linear24_wide_kernel, lds));
+    const int tiles = ((g.M + WIDE_TBM - 1) / WIDE_TBM) * ((g.N + WIDE_TBN - 1) / WIDE_TBN);
+    linear24_wide_kernel<<<dim3((unsigned)tiles), WIDE_NT, lds, st>>>(g);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
 }
 
 // y = bf16( bf16(sum of main slices + bias) + bf16(sum of second-product slices) )
@@ -929,6 +1252,41 @@ static int decode_path(const void* x, int64_t ldx, int64_t M, int64_t K, const v
     return q4 ? launch_decode<MODE_Q4, 2, MODE_NONE, 1>(a, a, st) : launch_decode<MODE_DENSE, 2, MODE_NONE, 1>(a, a, st);
 }
 
+#define PRESCALE_MIN_M 64
+// out[row][0 .. cols) = bf16(in[row][..] / div), 8 elements per thread (cols % 8 == 0); in place allowed
+__global__ __launch_bounds__(256) void div_rows_kernel(const bf16_t* in, int64_t ld_in, int64_t rows, int64_t cols, float div,
+                                                       bf16_t* out, int64_t ld_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, per_row = cols >> 3;
+    if (i >= rows * per_row) return;
+    const int64_t row = i / per_row, c = (i - row * per_row) * 8;
+    u16x8 v = *(const u16x8*)(in + row * ld_in + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16(bf16_to_f32(v[j]) / div);
+    *(u16x8*)(out + row * ld_out + c) = v;
+}
+static int launch_div_rows(const bf16_t* in, int64_t ld_in, int64_t rows, int64_t cols, float div, bf16_t* out, int64_t ld_out,
+                           hipStream_t st) {
+    div_rows_kernel<<<(unsigned)ceil_div64(rows * (cols >> 3), 256), 256, 0, st>>>(in, ld_in, rows, cols, div, out, ld_out);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// Whether a batch of M rows runs on the wide tile (linear24_wide_kernel, with the first adapter product as an NT GEMM) or on
+// the 128 x 128 tile.  The wide tile wants a grid that fills most of the 256 CUs with one workgroup each; below that the
+// smaller tile's finer grid wins (28672 x 8192: 0.21 against 0.32 ms at 256 rows, 0.38 against 0.33 ms at 512).
+// slim_linear24_set_wide / SLIM_FWD_WIDE: -1 the rule, 0 never, 1 whenever the kernel can run (M > PRESCALE_MIN_M).
+static int g_wide_mode = [] {
+    const char* e = getenv("SLIM_FWD_WIDE");
+    return e && *e ? atoi(e) : -1;
+}();
+extern "C" void slim_linear24_set_wide(int mode) { g_wide_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
+static int pick_wide_tile(int64_t M, int64_t N) {
+    if (M <= PRESCALE_MIN_M || g_wide_mode == 0) return 0;
+    if (g_wide_mode > 0) return 1;
+    const int64_t tiles = ((M + WIDE_TBM - 1) / WIDE_TBM) * ((N + WIDE_TBN - 1) / WIDE_TBN);
+    return M >= 256 && tiles >= 192;
+}
+
 extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r) {
     if (M <= 0 || N <= 0 || K <= 0 || r < 0) return -1;
     const int64_t r128 = round_up(r, 128);
@@ -945,6 +1303,7 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
         slab = b > slab ? b : slab;
     }
     int64_t total = t_bytes + slab;
+    if (M > PRESCALE_MIN_M && r > 0) total += round_up(M * K * 2, 256);      // bf16(x / a_div), written once per call
     if (M <= DECODE_MAX_M) {     // the small-batch path may be taken instead: keep the larger of the two
         const int64_t d = decode_ws_bytes(M, N, r);
         total = d > total ? d : total;
@@ -979,6 +1338,12 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
     if (M <= DECODE_MAX_M && N * K >= DECODE_MIN_WEIGHT)
         return decode_path(x, ldx, M, K, vals, meta, sf, N, bias, LeffT, ReffT, nullptr, nullptr, nullptr, nullptr, 0, r, a_div,
                            y, ldy, ws, st);
+    const int wide = pick_wide_tile(M, N);
+    // From PRESCALE_MIN_M rows on, the hook's two divisions by sqrt(rank) are made once per element by a streaming kernel
+    // instead of once per element and column tile inside the products (an IEEE division is ~10 instructions; the second
+    // product has N / 128 column tiles).
+    const bool prescale = M > PRESCALE_MIN_M && r > 0 && a_div != 1.f;
+    const float kernel_div = prescale ? 1.f : a_div;
     if (r > 0) {
         SLIM_REQUIRE(((uintptr_t)LeffT % 16) == 0 && ((uintptr_t)ReffT % 16) == 0,
                      "slim_linear24_forward: adapter operands must be 16-byte aligned");
@@ -986,20 +1351,51 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
         t = (bf16_t*)ws;
         ws += t_bytes;
         ws_left -= t_bytes;
+        const bf16_t* xa = (const bf16_t*)x;
+        int64_t ldxa = ldx;
+        if (prescale) {
+            bf16_t* xs = (bf16_t*)ws;
+            const int64_t xs_bytes = round_up(M * K * 2, 256);
+            ws += xs_bytes;
+            ws_left -= xs_bytes;
+            const int rc = launch_div_rows((const bf16_t*)x, ldx, M, K, a_div, xs, K, st);
+            if (rc != SLIM_OK) return rc;
+            xa = xs;
+            ldxa = K;
+        }
         // t = bf16( bf16(x / a_div) L_eff ): L_eff^T is [r128, K], rows >= r zero, so t[:, r:] = 0
-        FwdArgs g1{};
-        g1.M = (int)M;
-        g1.N = (int)r128;
-        g1.a = (const bf16_t*)x;
-        g1.lda = ldx;
-        g1.Bt = (const bf16_t*)LeffT;
-        g1.ldb = K;
-        g1.Ka = (int)K;
-        g1.a_div = a_div;
-        g1.y = t;
-        g1.ldy = r128;
-        const int rc = run_linear24(g1, ws, ws_left, st);
-        if (rc != SLIM_OK) return rc;
+        if (wide) {
+            GemmArgs gt;
+            gt.A = xa;
+            gt.lda = ldxa;
+            gt.B = (const bf16_t*)LeffT;
+            gt.ldb = K;
+            gt.M = (int)M;
+            gt.N = (int)r128;
+            gt.Kd = (int)K;
+            gt.C16 = t;
+            gt.ldc16 = r128;
+            const int rc = slim_gemm_launch(gt, st);
+            if (rc != SLIM_OK) return rc;
+        } else {
+            FwdArgs g1{};
+            g1.M = (int)M;
+            g1.N = (int)r128;
+            g1.a = xa;
+            g1.lda = ldxa;
+            g1.Bt = (const bf16_t*)LeffT;
+            g1.ldb = K;
+            g1.Ka = (int)K;
+            g1.a_div = kernel_div;
+            g1.y = t;
+            g1.ldy = r128;
+            const int rc = run_linear24(g1, ws, ws_left, st);
+            if (rc != SLIM_OK) return rc;
+        }
+        if (prescale) {
+            const int rc = launch_div_rows(t, r128, M, r128, a_div, t, r128, st);
+            if (rc != SLIM_OK) return rc;
+        }
     }
     FwdArgs g{};
     g.x = (const bf16_t*)x;
@@ -1019,10 +1415,14 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
         g.Bt = (const bf16_t*)ReffT;
         g.ldb = r8;
         g.Ka = (int)r8;
-        g.a_div = a_div;
+        g.a_div = kernel_div;
     }
     g.y = (bf16_t*)y;
     g.ldy = ldy;
+    if (wide) {
+        // both products in one launch on the wide tile (the divisions by sqrt(rank) were made beforehand: a_div is 1 here)
+        return launch_linear24_wide(g, st);
+    }
     return run_linear24(g, ws, ws_left, st);
 }
 

@@ -11,11 +11,11 @@ from .utils import get_layers_list, find_layers
 
 
 # From this many rows on, the forward expands the packed weight into a transient dense bf16 tensor (one streaming
-# kernel, 2 B written per element) and multiplies with the library GEMM (hipBLASLt through torch.matmul): at large
-# batches the product is MFMA-bound, the expansion costs < 10 % of it, and the tuned library kernel is ahead of
-# the fused one there (measured cross-over between 256 and 1024 rows; tools/forward_bench.py).  Storage stays
-# packed; results are those of the reference's emulated forward bit for bit (same GEMMs, same operands).
-LARGE_BATCH = int(__import__("os").environ.get("SLIM_PACKED_LARGE_BATCH", "512"))
+# kernel, 2 B written per element) and multiplies with the library GEMM (hipBLASLt through torch.matmul).  Off by
+# default: the library's own large-batch kernel (128 x 512 tile, sparse MFMA) is level with or ahead of the dense
+# emulated forward from 512 rows on, and the expansion costs 0.1 ms per call on top of the dense product (28672 x 8192:
+# 0.75 x the emulated forward at 512-1024 rows).  Storage stays packed either way.
+LARGE_BATCH = int(__import__("os").environ.get("SLIM_PACKED_LARGE_BATCH", str(1 << 30)))
 # Keep 4-bit group-quantised adapters as codes + scales for the small-batch path (0.5 instead of 2 bytes per
 # adapter element in HBM).  Off by default: rebuilding bf16(code / 7 * alpha) in registers costs more VALU time
 # than the bytes save on MI355X (28672 x 8192, rank 1024, batch 1: 81 us against 63 us with bf16 operands), so it
