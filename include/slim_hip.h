@@ -435,8 +435,8 @@ int slim_unpack24_int4(const void* vals, const void* meta, const float* sf, int6
  * Unquantised adapters (prune.py:317-321): L_eff = bf16(lora_left / sqrt(rank)), same for R_eff, a_div = 1.
  * Quantised adapters (prune.py:304-315): L_eff / R_eff = the group fake-quantised adapters, a_div = sqrt(rank). */
 int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r);
-/* Which kernel runs batches of more than 64 rows: -1 the library's rule (the 128 x 512 tile when its grid covers most of the
- * chip, else the 128 x 128 tile), 0 always the 128 x 128 tile, 1 always the 128 x 512 tile.  Results do not depend on the
+/* Which kernel runs batches of more than 64 rows: -1 the library's rule (the 128 x 256 tile with wave-private weight rows
+ * when its grid covers most of the chip, else the 128 x 128 tile), 0 always the 128 x 128 tile, 1 always the 128 x 256 tile.  Results do not depend on the
  * choice (both accumulate the reduction in the same order).  A test and tuning aid; no counterpart in the reference. */
 void slim_linear24_set_wide(int mode);
 int slim_linear24_forward(const void* x_bf16, int64_t ldx, int64_t M, int64_t K, const void* vals, const void* meta,

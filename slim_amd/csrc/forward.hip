@@ -509,11 +509,11 @@ __global__ __launch_bounds__(256, (WAVES_M * FR_M <= 8 ? 2 : 1)) void linear24_k
         }
 }
 
-// Main product alone on a wide tile, for batches of hundreds of rows and more.  The 128 x 128 tile above is bound by the
-// LDS, not by the matrix pipe: per K-step it expands the packed tile through randomly addressed table reads (bank
-// conflicts), writes it to LDS and reads every fragment back, for only 16 sparse instructions per wave.  Here a workgroup
-// of 8 waves owns 128 activation rows x 512 weight rows, and wave w owns weight rows 64 w .. 64 w + 63 of the panel against
-// ALL 128 activation rows:
+// Both products on a tile for batches of hundreds of rows and more.  The 128 x 128 tile above is bound by the LDS, not by the
+// matrix pipe: per K-step it expands the packed tile through randomly addressed table reads (bank conflicts), writes it to
+// LDS and reads every fragment back, for only 16 sparse instructions per wave.  Here a workgroup of 4 waves owns 128
+// activation rows x 256 weight rows, and wave w owns weight rows 64 w .. 64 w + 63 of the panel against ALL 128 activation
+// rows:
 //   * the weight never passes through LDS: a lane loads the packed bytes of its own operand slots straight from memory
 //     (per instruction 4 code bytes + 16 position bits; the 16 lanes of a row group read 2 x 128 contiguous bytes) and turns
 //     them into levels in registers;
@@ -521,12 +521,15 @@ __global__ __launch_bounds__(256, (WAVES_M * FR_M <= 8 ? 2 : 1)) void linear24_k
 //     every lane reads its own bank, so a lookup costs the conflict-free 2 cycles instead of ~7;
 //   * only the activation tile is staged in LDS (two buffers, one barrier per K-step), read by every wave as 8 row blocks
 //     for 8 x 4 sparse instructions, two row blocks at a time so that the reads of the next pair overlap the instructions
-//     of the current one.
-// Per K-step and CU: ~1000 LDS cycles against ~1100 matrix cycles (two waves per SIMD), where the 128 x 128 tile needs
-// ~2500 for a quarter of the products.  No split reduction; the second product follows in the same launch (below).
+//     of the current one;
+//   * two workgroups per CU (72 KiB of LDS and 256 registers per lane each): the waves of one workgroup reach the barrier
+//     of a K-step together, so their matrix instructions and their loads / LDS traffic alternate instead of overlapping;
+//     the second workgroup runs out of phase and fills the gaps (one workgroup of 8 waves on a 128 x 512 tile: 1.68 ms
+//     against 1.58 ms at 4096 rows, 0.98 against 0.85 ms at 2048).
+// No split reduction; the second product follows in the same launch (below).
 #define WIDE_TBM 128
-#define WIDE_TBN 512
-#define WIDE_NT 512
+#define WIDE_TBN 256
+#define WIDE_NT 256
 // LDS row strides (bf16 elements) of the activation tiles: 64 + 16 and 32 + 16.  With these the 16 lanes that a ds_read_b128
 // serves per cycle (rows r, r + 12 .. and the neighbouring 8-channel piece of rows r + 4 ..) fall on 16 different groups of four
 // banks; 64 + 8 and 32 + 8 put two of them on the same banks (38 % of the LDS cycles were conflict cycles).
@@ -741,8 +744,9 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
     for (int i = 0; i < FR_M; ++i)
 #pragma unroll
         for (int j = 0; j < FR_N; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NA2 = TBM * 4 / NT;                      // 16-byte pieces of the 32-channel tile of `a` per thread
     struct Regs2 {
-        u16x8 ra;
+        u16x8 ra[NA2];
         u16x8 b[FR_N];
     };
     // (the thread index passes through an empty asm statement so that the addresses of this phase are computed here and do not
@@ -750,9 +754,14 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
     int t2 = t;
     asm volatile("" : "+v"(t2));
     const int fr2 = t2 & 15, fq2 = (t2 >> 4) & 3, wave2 = t2 >> 6;
-    int arow = row0 + (t2 >> 2);
-    arow = arow < g.M ? arow : g.M - 1;
-    const bf16_t* ap = g.a + (int64_t)arow * g.lda + (t2 & 3) * 8;
+    const bf16_t* ap[NA2];
+#pragma unroll
+    for (int i = 0; i < NA2; ++i) {
+        const int c = t2 + NT * i;
+        int arow = row0 + (c >> 2);
+        arow = arow < g.M ? arow : g.M - 1;
+        ap[i] = g.a + (int64_t)arow * g.lda + (c & 3) * 8;
+    }
     const bf16_t* bp[FR_N];
 #pragma unroll
     for (int j = 0; j < FR_N; ++j) {
@@ -763,13 +772,18 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
     auto load2 = [&](Regs2& r, int kt) {
         // (a piece past Ka is fetched from the start of the row and zeroed where it is used: zeroing it here would make the
         // loop wait for the load at once)
-        r.ra = *(const u16x8*)(ap + kt * 32);
+#pragma unroll
+        for (int i = 0; i < NA2; ++i) r.ra[i] = *(const u16x8*)(ap[i] + kt * 32);
         const int k = kt * 32 + fq2 * 8 < g.Ka ? kt * 32 : 0;
 #pragma unroll
         for (int j = 0; j < FR_N; ++j) r.b[j] = *(const u16x8*)(bp[j] + k);
     };
     auto store2 = [&](const Regs2& r, int buf) {
-        *(u16x8*)(wsmem + buf * XBYTES2 + ((t >> 2) * WSTRIDE2 + (t & 3) * 8) * 2) = r.ra;
+#pragma unroll
+        for (int i = 0; i < NA2; ++i) {
+            const int c = t + NT * i;
+            *(u16x8*)(wsmem + buf * XBYTES2 + ((c >> 2) * WSTRIDE2 + (c & 3) * 8) * 2) = r.ra[i];
+        }
     };
     auto step2 = [&](Regs2& r, int buf, int kt, int kt_next) {
         const bf16_t* a_base = (const bf16_t*)(wsmem + buf * XBYTES2) + fr * WSTRIDE2 + fq * 8;
@@ -1272,8 +1286,8 @@ static int launch_div_rows(const bf16_t* in, int64_t ld_in, int64_t rows, int64_
 }
 
 // Whether a batch of M rows runs on the wide tile (linear24_wide_kernel, with the first adapter product as an NT GEMM) or on
-// the 128 x 128 tile.  The wide tile wants a grid that fills most of the 256 CUs with one workgroup each; below that the
-// smaller tile's finer grid wins (28672 x 8192: 0.21 against 0.32 ms at 256 rows, 0.38 against 0.33 ms at 512).
+// the 128 x 128 tile.  The wide tile wants a grid that fills most of the 512 workgroup slots of the chip; below that the
+// smaller tile's finer grid wins (28672 x 8192: 0.21 against 0.26 ms at 256 rows, 0.38 against 0.32 ms at 512).
 // slim_linear24_set_wide / SLIM_FWD_WIDE: -1 the rule, 0 never, 1 whenever the kernel can run (M > PRESCALE_MIN_M).
 static int g_wide_mode = [] {
     const char* e = getenv("SLIM_FWD_WIDE");
@@ -1284,7 +1298,7 @@ static int pick_wide_tile(int64_t M, int64_t N) {
     if (M <= PRESCALE_MIN_M || g_wide_mode == 0) return 0;
     if (g_wide_mode > 0) return 1;
     const int64_t tiles = ((M + WIDE_TBM - 1) / WIDE_TBM) * ((N + WIDE_TBN - 1) / WIDE_TBN);
-    return M >= 256 && tiles >= 192;
+    return M >= 256 && tiles >= 384;
 }
 
 extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r) {

@@ -12,7 +12,7 @@ from .utils import get_layers_list, find_layers
 
 # From this many rows on, the forward expands the packed weight into a transient dense bf16 tensor (one streaming
 # kernel, 2 B written per element) and multiplies with the library GEMM (hipBLASLt through torch.matmul).  Off by
-# default: the library's own large-batch kernel (128 x 512 tile, sparse MFMA) is level with or ahead of the dense
+# default: the library's own large-batch kernel (128 x 256 tile, sparse MFMA) is level with or ahead of the dense
 # emulated forward from 512 rows on, and the expansion costs 0.1 ms per call on top of the dense product (28672 x 8192:
 # 0.75 x the emulated forward at 512-1024 rows).  Storage stays packed either way.
 LARGE_BATCH = int(__import__("os").environ.get("SLIM_PACKED_LARGE_BATCH", str(1 << 30)))

@@ -116,7 +116,7 @@ CASES = [
     (256, 512, 128, False, 128, [1, 16, 64, 200]),
     (1024, 4096, 409, False, None, [1, 16, 48, 1000]),
     (4096, 1024, 256, True, 128, [2, 128, 513]),
-    # 9 tiles of 128 rows: the last 512-row panel of the wide tile is a quarter full
+    # 9 tiles of 128 rows: the last 256-row panel of the wide tile is half full
     (1152, 512, 51, True, None, [100, 300, 513]),
     (1152, 512, 128, False, 128, [129, 640]),
     # the forward microbenchmark's layer (LLaMA-3-70B up/gate projection, 10 % rank adapters), quantised and bf16 adapters
@@ -164,7 +164,7 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
         slack = scale * 2.0 ** -8 * math.sqrt(1e-3 * y.numel())
         assert err_ours <= err_ref * 1.25 + slack, (M, err_ours, err_ref)
         if M > 64:
-            # the 128 x 128 tile and the 128 x 512 tile (with the first adapter product as an NT GEMM), whichever of them
+            # the 128 x 128 tile and the 128 x 256 tile (with the first adapter product as an NT GEMM), whichever of them
             # the library's rule picked above: the same bounds, and identical outputs wherever neither path splits a
             # reduction into slices (both then accumulate in the same order; the small layers here)
             from slim_amd import _lib
