@@ -687,6 +687,21 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
     const bool wide = (g.ldy & 3) == 0 && ((uintptr_t)g.y & 7) == 0;
     // (all loads of an epilogue are issued before the first value is used, from clamped addresses and without branches: a
     // load inside a guarded block is waited for on the spot, 32 memory round trips in a row per workgroup)
+    //
+    // 16-byte accesses: a lane holds 4 consecutive outputs (8 bytes) of a row per 16 x 16 block.  For a pair of neighbouring
+    // blocks (j, j + 1) v_permlane16_swap exchanges the odd 16-lane rows of the first block's registers with the even rows of
+    // the second's: afterwards the lanes with even fq hold 8 consecutive outputs of block j (their own 4 and those of lane
+    // fq + 1), the lanes with odd fq 8 consecutive outputs of block j + 1 -- one 16-byte store per lane and pair instead of two
+    // 8-byte ones (the epilogue is bound by the number of store instructions).  The swap is its own inverse, which the
+    // read-back of the first term uses.
+    const bool wide16 = (g.ldy & 7) == 0 && ((uintptr_t)g.y & 15) == 0;
+    auto swap_pair = [&](uint2& x, uint2& y) {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        x = make_uint2(r0[0], r1[0]);
+        y = make_uint2(r0[1], r1[1]);
+    };
+    auto pack4 = [&](const bf16_t (&o)[4]) { return make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)); };
     auto write_out = [&](bool add_to_y) {
         float bv[FR_N][4];
 #pragma unroll
@@ -694,6 +709,54 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
             const int n = min(col0 + wave * 64 + j * 16 + fq * 4, g.N - 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[j][r] = (!add_to_y && g.bias) ? bf16_to_f32(g.bias[n + r]) : 0.f;
+        }
+        if (wide16) {
+            // lane's 16-byte piece of the pair (jp, jp + 1): block jp + (fq & 1), outputs 4 (fq & 2) .. + 7 of it
+            const int n16 = col0 + wave * 64 + (fq & 1) * 16 + (fq & 2) * 4;
+            uint4 prev[FR_M][FR_N / 2];
+            if (add_to_y) {
+#pragma unroll
+                for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+                    for (int jp = 0; jp < FR_N; jp += 2) {
+                        const int m = min(row0 + i * 16 + fr, g.M - 1);
+                        const int n = min(n16 + jp * 16, g.N - 8);
+                        prev[i][jp / 2] = *(const uint4*)(g.y + (int64_t)m * g.ldy + n);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+                for (int jp = 0; jp < FR_N; jp += 2) {
+                    uint2 v[2];
+                    if (add_to_y) {
+                        uint2 h0 = make_uint2(prev[i][jp / 2].x, prev[i][jp / 2].y), h1 = make_uint2(prev[i][jp / 2].z, prev[i][jp / 2].w);
+                        swap_pair(h0, h1);              // back to one block per register pair
+                        const uint2 h[2] = {h0, h1};
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const bf16_t hh[4] = {(bf16_t)(h[q].x & 0xffffu), (bf16_t)(h[q].x >> 16), (bf16_t)(h[q].y & 0xffffu), (bf16_t)(h[q].y >> 16)};
+                            bf16_t o[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(bf16_to_f32(hh[r]) + round_bf16(acc[i][jp + q][r]));
+                            v[q] = pack4(o);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            bf16_t o[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(acc[i][jp + q][r] + bv[jp + q][r]);
+                            v[q] = pack4(o);
+                        }
+                    }
+                    swap_pair(v[0], v[1]);
+                    const int m = row0 + i * 16 + fr;
+                    const int n = n16 + jp * 16;
+                    if (m >= g.M || n >= g.N) continue;
+                    *(uint4*)(g.y + (int64_t)m * g.ldy + n) = make_uint4(v[0].x, v[0].y, v[1].x, v[1].y);
+                }
+            return;
         }
         uint2 prev[FR_M][FR_N];
         if (add_to_y) {
@@ -726,7 +789,7 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
                 }
                 if (m >= g.M || n >= g.N) continue;
                 bf16_t* dst = g.y + (int64_t)m * g.ldy + n;
-                if (wide) *(uint2*)dst = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+                if (wide) *(uint2*)dst = pack4(o);
                 else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[r] = o[r];
