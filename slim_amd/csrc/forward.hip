@@ -1364,6 +1364,17 @@ static int pick_wide_tile(int64_t M, int64_t N) {
     return M >= 256 && tiles >= 384;
 }
 
+// Slices of the reduction of t = x L_eff (an [M, r128] output with a long reduction) on the wide path: its 128 x 128 tiles
+// alone leave most of the chip idle (1024 rows, rank 1024: 64 tiles), so the reduction is cut until about 512 workgroups
+// run; the slab stays below 34 MB (slices x tiles <= 512).  Short reductions (K < 2048) are not cut.
+static int wide_t_splits(int64_t M, int64_t r128, int64_t K) {
+    const int64_t tiles = ((M + 127) / 128) * (r128 / 128), nk = K / FBK;
+    if (tiles <= 0 || nk < 32) return 1;
+    int64_t s = 512 / tiles;
+    s = s < 1 ? 1 : (s > 8 ? 8 : s);
+    return (int)s;
+}
+
 extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r) {
     if (M <= 0 || N <= 0 || K <= 0 || r < 0) return -1;
     const int64_t r128 = round_up(r, 128);
@@ -1377,6 +1388,10 @@ extern "C" int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K
         int sm, sa;
         plan_splits(tiles, M, n, pass ? (int)(K / FBK) : 0, pass ? (int)((round_up(r, 8) + FBK - 1) / FBK) : (int)(K / FBK), &sm, &sa);
         const int64_t b = (int64_t)(sm + sa) * M * n * 4;
+        slab = b > slab ? b : slab;
+    }
+    if (M > PRESCALE_MIN_M && r > 0) {
+        const int64_t b = (int64_t)wide_t_splits(M, r128, K) * M * r128 * 4;  // slices of t = x L on the wide path
         slab = b > slab ? b : slab;
     }
     int64_t total = t_bytes + slab;
@@ -1452,6 +1467,12 @@ extern "C" int slim_linear24_forward(const void* x, int64_t ldx, int64_t M, int6
             gt.Kd = (int)K;
             gt.C16 = t;
             gt.ldc16 = r128;
+            const int splits = wide_t_splits(M, r128, K);
+            if (splits > 1) {
+                gt.slab = (float*)ws;
+                gemm_plan_splits(gt, splits);
+                if (gt.splits <= 1) gt.slab = nullptr;
+            }
             const int rc = slim_gemm_launch(gt, st);
             if (rc != SLIM_OK) return rc;
         } else {

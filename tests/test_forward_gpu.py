@@ -166,7 +166,7 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
         if M > 64:
             # the 128 x 128 tile and the 128 x 256 tile (with the first adapter product as an NT GEMM), whichever of them
             # the library's rule picked above: the same bounds, and identical outputs wherever neither path splits a
-            # reduction into slices (both then accumulate in the same order; the small layers here)
+            # reduction into slices (both then accumulate in the same order; the small layers with short reductions here)
             from slim_amd import _lib
             for mode in (0, 1):
                 try:
@@ -176,7 +176,7 @@ def test_packed_forward_matches_emulated_forward(ops, N, K, r, bias, qblock, bat
                     _lib.query("slim_linear24_set_wide", -1)
                 assert (y_m.double() - ref.double()).abs().max().item() <= scale * 2.0 ** -6, (M, mode)
                 assert (y_m.double() - exact).norm().item() <= err_ref * 1.25 + slack, (M, mode)
-                if N <= 4096:
+                if N <= 4096 and K < 2048:
                     assert torch.equal(y_m, y), (M, mode, (y_m != y).sum().item())
         if M >= 512:
             # the optional transient dense expansion + library GEMMs: the reference's own operations, bit for bit
