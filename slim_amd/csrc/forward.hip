@@ -1349,8 +1349,9 @@ static int launch_div_rows(const bf16_t* in, int64_t ld_in, int64_t rows, int64_
 }
 
 // Whether a batch of M rows runs on the wide tile (linear24_wide_kernel, with the first adapter product as an NT GEMM) or on
-// the 128 x 128 tile.  The wide tile wants a grid that fills most of the 512 workgroup slots of the chip; below that the
-// smaller tile's finer grid wins (28672 x 8192: 0.21 against 0.26 ms at 256 rows, 0.38 against 0.32 ms at 512).
+// the 128 x 128 tile.  The wide tile wants a grid of a couple of hundred workgroups; below that the smaller tile's finer grid
+// (and its split reduction) wins (28672 x 8192, tiled against wide: 0.147 / 0.177 ms at 128 rows, 0.203 / 0.174 at 192,
+// 0.203 / 0.176 at 256, 0.316 / 0.228 at 384).
 // slim_linear24_set_wide / SLIM_FWD_WIDE: -1 the rule, 0 never, 1 whenever the kernel can run (M > PRESCALE_MIN_M).
 static int g_wide_mode = [] {
     const char* e = getenv("SLIM_FWD_WIDE");
@@ -1361,7 +1362,7 @@ static int pick_wide_tile(int64_t M, int64_t N) {
     if (M <= PRESCALE_MIN_M || g_wide_mode == 0) return 0;
     if (g_wide_mode > 0) return 1;
     const int64_t tiles = ((M + WIDE_TBM - 1) / WIDE_TBM) * ((N + WIDE_TBN - 1) / WIDE_TBN);
-    return M >= 256 && tiles >= 384;
+    return M >= 160 && tiles >= 192;
 }
 
 // Slices of the reduction of t = x L_eff (an [M, r128] output with a long reduction) on the wide path: its 128 x 128 tiles
