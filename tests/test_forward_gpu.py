@@ -241,3 +241,34 @@ def test_packed_checkpoint_round_trip(ops, tmp_path):
             assert torch.equal(sa[t], sb[t]), (ka, t)
     with torch.no_grad():
         assert torch.equal(fresh(ids).logits, ref)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pad_x,pad_y,off_y", [(8, 8, 0), (16, 4, 0), (8, 3, 0), (8, 8, 4)])
+def test_forward_with_strided_activations_and_outputs(ops, mode, pad_x, pad_y, off_y):
+    """slim_linear24_forward through the C ABI with row strides larger than the row length (x: a multiple of 8 elements;
+    y: any) and an output pointer that is only 8-byte aligned, on both tiles: the same values as the contiguous call
+    (the kernels' 16-, 8- and 2-byte store paths), and nothing written between the rows."""
+    from slim_amd import _lib
+    from slim_amd.packed import PackedLinear
+    N, K, r, M = 1152, 512, 51, 300
+    lin = build_layer(N, K, r, seed=77, bias=True)
+    p = PackedLinear(lin)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(DEV)
+    try:
+        _lib.query("slim_linear24_set_wide", mode)
+        ref = p(x)
+        xs = torch.zeros(M, K + pad_x, dtype=torch.bfloat16, device=DEV)
+        xs[:, :K] = x
+        ybuf = torch.full((M * (N + pad_y) + 16,), 7.0, dtype=torch.bfloat16, device=DEV)
+        need = _lib.query("slim_linear24_workspace_bytes", M, N, K, r)
+        ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+        _lib.call("slim_linear24_forward", xs.data_ptr(), K + pad_x, M, K, p.vals.data_ptr(), p.meta.data_ptr(),
+                  p.sf.data_ptr(), N, p.bias.data_ptr(), p.LeffT.data_ptr(), p.ReffT.data_ptr(), r, float(p.a_div),
+                  ybuf.data_ptr() + 2 * off_y, N + pad_y, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        _lib.query("slim_linear24_set_wide", -1)
+    y = ybuf[off_y:off_y + M * (N + pad_y)].reshape(M, N + pad_y)
+    assert torch.equal(y[:, :N], ref)
+    assert bool((y[:, N:] == 7.0).all()) and bool((ybuf[:off_y] == 7.0).all())
