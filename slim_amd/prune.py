@@ -260,15 +260,65 @@ def add_lora_hook(module, input, output):
             module.lora_right / torch.sqrt(module.lora_rank))
 
 
-def _run_block(layer, src, dst, kwargs, batch):
+class _StopBlock(Exception):
+    """Raised by the statistics hook of the last linear of a block: nothing after it is needed."""
+
+
+def _run_block(layer, src, dst, kwargs, batch, after_batch=None):
+    """layer(src) in batches of `batch` samples into dst.  A batch whose forward ends with _StopBlock (raised by a hook)
+    leaves its part of dst as it is; after_batch(index) runs after every batch."""
     n = src.shape[0]
     with torch.no_grad():
-        for j in range(0, n, batch):
-            with shared_inputs():       # q/k/v (gate/up) read one tensor: its column sums are computed once
-                out = layer(src[j:j + batch], **kwargs)
-            if isinstance(out, (tuple, list)):      # older decoder layers return (hidden_states, ...)
-                out = out[0]
-            dst[j:j + batch] = out
+        for b, j in enumerate(range(0, n, batch)):
+            try:
+                with shared_inputs():       # q/k/v (gate/up) read one tensor: its column sums are computed once
+                    out = layer(src[j:j + batch], **kwargs)
+                if isinstance(out, (tuple, list)):      # older decoder layers return (hidden_states, ...)
+                    out = out[0]
+                dst[j:j + batch] = out
+            except _StopBlock:
+                pass
+            if after_batch is not None:
+                after_batch(b)
+
+
+# The statistics pass of a block only needs the INPUTS of its linears; its output is overwritten by the pass that follows
+# the compression (prune.py:362-364).  So from the second batch on, the linear that the first batch showed to run last
+# takes its statistics in a pre-hook and ends the block's forward there: its own product (in LLaMA the 11008 -> 4096
+# down projection, a fifth of the block's GEMM work) and whatever follows it are never computed.  Statistics are
+# unchanged (the same tensors reach the same linears).
+STATS_EARLY_EXIT = os.environ.get("SLIM_STATS_EARLY_EXIT", "1") == "1"
+
+
+def gather_block_statistics(layer, subset, wrapped_layers, inps, outs, kwargs, batch):
+    """The forward pass of prune.py:247-254: every linear's wrapper sees every calibration sample's input."""
+    order = []
+
+    def add_batch(name):
+        def tmp(_, inp, out):
+            order.append(name)
+            wrapped_layers[name].add_batch(inp[0].data, out.data, per_sample=True)
+        return tmp
+
+    handles = {name: subset[name].register_forward_hook(add_batch(name)) for name in wrapped_layers}
+
+    def after_batch(b):
+        if b != 0 or not STATS_EARLY_EXIT or sorted(order) != sorted(wrapped_layers):
+            return          # (a linear that ran twice or not at all: keep the plain pass)
+        last = order[-1]
+
+        def pre(_, args):
+            wrapped_layers[last].add_batch(args[0].data, None, per_sample=True)
+            raise _StopBlock
+
+        handles[last].remove()
+        handles[last] = subset[last].register_forward_pre_hook(pre)
+
+    try:
+        _run_block(layer, inps, outs, kwargs, batch, after_batch)
+    finally:
+        for h in handles.values():
+            h.remove()
 
 
 COND_WORD = 63        # SLIM_FIT_INFO_COND_WORD of the last 64-word status block of a fit
@@ -634,15 +684,7 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         subset = find_layers(layer)
         wrapped_layers = {name: WrappedGPT(subset[name], defer=world > 1) for name in subset}
 
-        def add_batch(name):
-            def tmp(_, inp, out):
-                wrapped_layers[name].add_batch(inp[0].data, out.data, per_sample=True)
-            return tmp
-
-        handles = [subset[name].register_forward_hook(add_batch(name)) for name in wrapped_layers]
-        _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
-        for h in handles:
-            h.remove()
+        gather_block_statistics(layer, subset, wrapped_layers, inps, outs, kwargs, CALIBRATION_BATCH)
 
         # shift_zeros (prune.py:261-262), then the `any(scaler_row == 0)` guard of add_lora (lora.py:139, which
         # sees the shifted statistics) for every linear with a single host synchronisation
