@@ -426,7 +426,7 @@ int slim_pack24_int4(const void* W_bf16, const float* sf, int64_t N, int64_t K, 
 /* Exact inverse (a dequantised -0 comes back as +0). */
 int slim_unpack24_int4(const void* vals, const void* meta, const float* sf, int64_t N, int64_t K, void* W_bf16,
                        void* stream);
-/* nn.Linear forward + add_lora_hook (slim/prune.py:303-321) from the packed weight (two launches; from 65 rows on two
+/* nn.Linear forward + add_lora_hook (slim/prune.py:303-321) from the packed weight (two launches; from 17 rows on two
  * more that divide by a_div once per element):
  *   t = bf16( bf16(x / a_div) L_eff ),   y = bf16( bf16(x W^T + bias) + bf16( bf16(t / a_div) R_eff ) ).
  * x bf16 [M, K] (row stride ldx), y bf16 [M, N] (row stride ldy), bias bf16 [N] or NULL.
@@ -435,7 +435,7 @@ int slim_unpack24_int4(const void* vals, const void* meta, const float* sf, int6
  * Unquantised adapters (prune.py:317-321): L_eff = bf16(lora_left / sqrt(rank)), same for R_eff, a_div = 1.
  * Quantised adapters (prune.py:304-315): L_eff / R_eff = the group fake-quantised adapters, a_div = sqrt(rank). */
 int64_t slim_linear24_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t r);
-/* Which kernel runs batches of more than 64 rows: -1 the library's rule (the 128 x 256 tile with wave-private weight rows
+/* Which kernel runs batches of more than 16 rows: -1 the library's rule (the 128 x 256 tile with wave-private weight rows
  * when its grid covers most of the chip, else the 128 x 128 tile), 0 always the 128 x 128 tile, 1 always the 128 x 256 tile.  Results do not depend on the
  * choice (both accumulate the reduction in the same order).  A test and tuning aid; no counterpart in the reference. */
 void slim_linear24_set_wide(int mode);

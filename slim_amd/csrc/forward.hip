@@ -1329,7 +1329,7 @@ static int decode_path(const void* x, int64_t ldx, int64_t M, int64_t K, const v
     return q4 ? launch_decode<MODE_Q4, 2, MODE_NONE, 1>(a, a, st) : launch_decode<MODE_DENSE, 2, MODE_NONE, 1>(a, a, st);
 }
 
-#define PRESCALE_MIN_M 64
+#define PRESCALE_MIN_M 16
 // out[row][0 .. cols) = bf16(in[row][..] / div), 8 elements per thread (cols % 8 == 0); in place allowed
 __global__ __launch_bounds__(256) void div_rows_kernel(const bf16_t* in, int64_t ld_in, int64_t rows, int64_t cols, float div,
                                                        bf16_t* out, int64_t ld_out) {
