@@ -598,14 +598,18 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
     const int64_t unit0 = ((int64_t)tn128 * ktiles * 2 + (fq >> 1)) * 128 + (wave & 1) * 64 + fr;
     const uint8_t* cp = g.vals + unit0 * 8 + (fq & 1) * 4;
     const uint8_t* mp = g.meta + unit0 * 4 + (fq & 1) * 2;
+    // (the position bits are reloaded AFTER the products that use them, into the same registers: requested together with the
+    // codes, before the products, they need registers of their own and a copy at the end of the loop body, and that copy
+    // makes the loop wait for every load in flight once per two K-steps)
     auto load = [&](Regs& r, int kt) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) r.ra[i] = *(const u16x8*)(xp[i] + (int64_t)kt * FBK);
 #pragma unroll
-        for (int j = 0; j < FR_N; ++j) {
-            r.code[j] = *(const uint32_t*)(cp + (int64_t)kt * 2048 + j * 128);
-            r.pos[j] = *(const unsigned short*)(mp + (int64_t)kt * 1024 + j * 64);
-        }
+        for (int j = 0; j < FR_N; ++j) r.code[j] = *(const uint32_t*)(cp + (int64_t)kt * 2048 + j * 128);
+    };
+    auto load_pos = [&](Regs& r, int kt) {
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) r.pos[j] = *(const unsigned short*)(mp + (int64_t)kt * 1024 + j * 64);
     };
     auto store = [&](const Regs& r, int buf) {
         char* xb = wsmem + buf * XBYTES;
@@ -626,14 +630,12 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
         };
         bf16x8 wf[FR_N];
-        int idx[FR_N];
         bf16x16 xa[2], xb[2];
 #pragma unroll
         for (int j = 0; j < FR_N; ++j) {
             const uint32_t c = r.code[j];
             const u32x4 v = {my_lut[(c & 0xffu) * 32], my_lut[((c >> 8) & 0xffu) * 32], my_lut[((c >> 16) & 0xffu) * 32], my_lut[(c >> 24) * 32]};
             wf[j] = __builtin_bit_cast(bf16x8, v);
-            idx[j] = (int)r.pos[j];
         }
         xa[0] = read_x(0);
         xa[1] = read_x(1);
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < FR_N; ++j)
-                    acc[2 * p + ii][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xa[ii], acc[2 * p + ii][j], idx[j], 0, 0);
+                    acc[2 * p + ii][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xa[ii], acc[2 * p + ii][j], (int)r.pos[j], 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (2 * p + 4 < FR_M) {
                 xa[0] = read_x(2 * p + 4);
@@ -658,9 +660,10 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < FR_N; ++j)
-                    acc[2 * p + 2 + ii][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xb[ii], acc[2 * p + 2 + ii][j], idx[j], 0, 0);
+                    acc[2 * p + 2 + ii][j] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(wf[j], xb[ii], acc[2 * p + 2 + ii][j], (int)r.pos[j], 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        load_pos(r, kt_next);
     };
 
     // K-steps two ahead in registers, the activation tile one ahead in LDS; every load and store unconditional (see
@@ -668,7 +671,9 @@ __global__ __launch_bounds__(WIDE_NT, 2) void linear24_wide_kernel(FwdArgs g) {
     const int nk = (int)ktiles, last = nk - 1;
     Regs regs[2];
     load(regs[0], 0);
+    load_pos(regs[0], 0);
     load(regs[1], min(1, last));
+    load_pos(regs[1], min(1, last));
     store(regs[0], 0);
     __syncthreads();                  // also publishes the table
     for (int kt = 0; kt < nk; kt += 2) {
