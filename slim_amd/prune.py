@@ -292,7 +292,7 @@ STATS_EARLY_EXIT = os.environ.get("SLIM_STATS_EARLY_EXIT", "1") == "1"
 
 def gather_block_statistics(layer, subset, wrapped_layers, inps, outs, kwargs, batch):
     """The forward pass of prune.py:247-254: every linear's wrapper sees every calibration sample's input."""
-    order = []
+    order = []              # the linears in the order they ran in the current batch
 
     def add_batch(name):
         def tmp(_, inp, out):
@@ -303,13 +303,17 @@ def gather_block_statistics(layer, subset, wrapped_layers, inps, outs, kwargs, b
     handles = {name: subset[name].register_forward_hook(add_batch(name)) for name in wrapped_layers}
 
     def after_batch(b):
-        if b != 0 or not STATS_EARLY_EXIT or sorted(order) != sorted(wrapped_layers):
+        first = list(order)
+        order.clear()
+        if b != 0 or not STATS_EARLY_EXIT or sorted(first) != sorted(wrapped_layers):
             return          # (a linear that ran twice or not at all: keep the plain pass)
-        last = order[-1]
+        last = first[-1]
 
         def pre(_, args):
             wrapped_layers[last].add_batch(args[0].data, None, per_sample=True)
-            raise _StopBlock
+            if len(order) == len(wrapped_layers) - 1:      # every other linear has had its input: nothing left to see
+                raise _StopBlock
+            order.append(last)                              # (a block that changed its order: run on)
 
         handles[last].remove()
         handles[last] = subset[last].register_forward_pre_hook(pre)
