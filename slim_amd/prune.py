@@ -729,9 +729,10 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                                 torch.float32 if slim_quant else torch.bfloat16, prune_lora,
                                 (prune_n, prune_m, bitwidth if (quantizer is not None and quantize_first) else 0))
 
-        progress_bar.set_description(f"Layer {i} - Evaluating Output")
-        _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
-        inps, outs = outs, inps
+        if i + 1 < len(layers):         # (the last block's outputs feed nothing)
+            progress_bar.set_description(f"Layer {i} - Evaluating Output")
+            _run_block(layer, inps, outs, kwargs, CALIBRATION_BATCH)
+            inps, outs = outs, inps
         if not KEEP_ON_DEVICE:
             layers[i] = layer.cpu()
         del layer
