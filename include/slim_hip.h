@@ -167,10 +167,34 @@ int slim_error_matrix(const void* W_bf16, const uint8_t* mask, const float* s, c
 int slim_error_matrix_deq(const void* W_bf16, const void* Wdeq_bf16, const uint8_t* mask, const float* s, int64_t N,
                           int64_t K, float* E_f32, void* E_bf16, void* stream);
 
+/* scale_important_weights, slim/lora.py:132-136 (and slim/prune.py:331-335): flags[c] = 1 for the `count` input channels
+ * with the largest scaler_row[c] * bf16(sum_rows |W[:, c]|) (the reference's column sums are a bf16 tensor), 0 elsewhere;
+ * equal metrics at the boundary: lower index first.  K a multiple of 8; workspace from the query. */
+int64_t slim_important_columns_workspace_bytes(int64_t N, int64_t K);
+int slim_important_columns(const void* W_bf16, const float* scaler_row, int64_t N, int64_t K, int64_t count, uint8_t* flags,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+/* Quantizer.scale_important_columns, quantization.py:160-170: out = bf16(float(in) * factor) in the flagged columns of
+ * in [N, K], a copy elsewhere (factor 2 before the codes are taken, 0.5 after dequantisation); out == in allowed. */
+int slim_scale_columns_bf16(const void* in, const uint8_t* flags, int64_t N, int64_t K, float factor, void* out, void* stream);
+/* The same on an fp32 matrix in place (the per-tensor quantiser's dequantised values, quantization.py:212-215). */
+int slim_scale_columns_f32(float* x, const uint8_t* flags, int64_t N, int64_t K, float factor, void* stream);
+/* slim_error_matrix in its general form (slim/lora.py:149-156 with quantization.py:156, :192, :212-215).
+ * col_flags (NULL: none): scale_important_weights -- in the flagged columns the code is that of the doubled weight and the
+ * dequantised value is halved, E = W * s - mask0(((code / sf) * 0.5) * s).
+ * deq_bf16 != 0: code / sf is rounded to bf16 before it is multiplied by s -- the abs-max quantiser's scale is a bf16
+ * (1, 1) tensor in the reference (quantization.py:190-194), which makes `quantized_mat / scaling_factor` a bf16 tensor;
+ * SLiM-Quant scales are fp32 and leave fp32 values (deq_bf16 = 0, what slim_error_matrix computes). */
+int slim_error_matrix_cols(const void* W_bf16, const uint8_t* mask, const float* s, const float* sf, int num_bits,
+                           const uint8_t* col_flags, int deq_bf16, int64_t N, int64_t K, float* E_f32, void* E_bf16,
+                           void* stream);
+
 /* slim_error_matrix (per-tensor quantiser or none, bf16 output) and the transpose of its result in one pass: E [N, K] and
  * Et [K, N]; N and K multiples of 8. */
 int slim_error_matrix_t(const void* W_bf16, const uint8_t* mask, const float* s, const float* sf, int num_bits, int64_t N,
                         int64_t K, void* E_bf16, void* Et_bf16, void* stream);
+/* The same with the dequantised values rounded to bf16 when deq_bf16 != 0 (abs-max quantiser, see slim_error_matrix_cols). */
+int slim_error_matrix_t_rounded(const void* W_bf16, const uint8_t* mask, const float* s, const float* sf, int num_bits,
+                                int deq_bf16, int64_t N, int64_t K, void* E_bf16, void* Et_bf16, void* stream);
 int slim_transpose_bf16(const void* in, int64_t R, int64_t C, void* out, void* stream);
 
 /* C[M, N] = alpha * A[M, Kd] * Bt[N, Kd]^T + beta * C_f32, bf16 operands (reduction dimension

@@ -21,7 +21,7 @@ __all__ = [
     "histogram_density", "compute_average_error", "find_optimal_quantization_cap",
     "num_bins_for", "quantize_per_tensor", "dequantize_per_tensor",
     "group_quant_params", "group_quantize", "group_dequantize",
-    "lora_rank_for", "add_lora", "quantize_input_fp8", "quantize_input_int",
+    "lora_rank_for", "add_lora", "important_columns", "group_fake_quantize", "quantize_input_fp8", "quantize_input_int",
     "compress_linear",
 ]
 
@@ -164,12 +164,22 @@ def find_optimal_quantization_cap(mat, num_bits, num_bins, return_trace=False):
     return val[idx]
 
 
-def quantize_per_tensor(mat, num_bits, slim_quant=True, abs_max=None):
+def important_columns(W, scaler_row):
+    """slim/lora.py:132-136 (and slim/prune.py:331-335): the 1 % of input channels with the largest
+    scaler_row * sum_rows |W| (the column sums are a bf16 tensor), as an index tensor in topk's order."""
+    metric = scaler_row * W.abs().sum(dim=0)
+    return metric.topk(int(0.01 * metric.numel()), largest=True, sorted=False)[1]
+
+
+def quantize_per_tensor(mat, num_bits, slim_quant=True, abs_max=None, important=None):
     """Quantizer.quantize_block, slim/quantization/quantization.py:173-200.
 
     Returns (codes int8, scaling_factor reshaped (1, 1)).  `mat * scaling_factor` keeps
     mat's dtype (a 0-d fp32 tensor does not promote bf16), so the product is rounded to
     bf16 before round-half-even.
+    important (index tensor, quantize_weight's important_columns): those columns are divided by 1/2 in
+    mat's dtype AFTER the clipping threshold has been found on the unscaled matrix (:184-192 with :160-168;
+    the reference scales in place and undoes it at :156).
     """
     max_q = 2 ** (num_bits - 1) - 1
     if abs_max is None:
@@ -177,15 +187,37 @@ def quantize_per_tensor(mat, num_bits, slim_quant=True, abs_max=None):
             abs_max = find_optimal_quantization_cap(mat, num_bits, num_bins_for(mat.numel()))
         else:
             abs_max = mat.abs().max()
+    if important is not None:
+        mat = mat.clone()
+        mat[:, important] /= 0.5
     scaling_factor = max_q / abs_max
     q = torch.round((mat * scaling_factor).float())
     q = torch.clamp(q, -max_q - 1, max_q)
     return q.to(torch.int8), scaling_factor.reshape(1, 1)
 
 
-def dequantize_per_tensor(codes, scaling_factor):
-    """Quantizer.dequantize_absmax, (1, 1) branch, slim/quantization/quantization.py:211-212."""
-    return codes / scaling_factor
+def dequantize_per_tensor(codes, scaling_factor, important=None):
+    """Quantizer.dequantize_absmax, (1, 1) branch, slim/quantization/quantization.py:211-215 (the important
+    columns, quantised at twice their size, are halved again)."""
+    deq = codes / scaling_factor
+    if important is not None:
+        deq[:, important] *= 0.5
+    return deq
+
+
+def group_fake_quantize(mat, block, num_bits, important=None):
+    """Quantizer.quantize_weight, block branch, followed by dequantize_absmax
+    (slim/quantization/quantization.py:139-148, :213-215): the group scales come from the unscaled matrix, the
+    important columns are doubled before the codes are taken and halved after dequantisation (bf16)."""
+    alphas = group_quant_params(mat, block)
+    src = mat
+    if important is not None:
+        src = mat.clone()
+        src[:, important] /= 0.5
+    deq = group_dequantize(group_quantize(src, alphas, num_bits), alphas, num_bits, dtype=mat.dtype)
+    if important is not None:
+        deq[:, important] *= 0.5
+    return deq, alphas
 
 
 # --------------------------------------------------------------------------------------
@@ -248,18 +280,28 @@ def lora_rank_for(shape, rank_ratio, tile):
     return rank
 
 
-def add_lora(W, W_mask, scaler_row, rank_ratio, num_bits=4, tile=None, slim_lora=True, quantize=True):
-    """slim/lora.py:105-213, branch separate_lora=True, quantize_first=True, no prune_lora,
-    no scale_important_weights.  Returns dict(weight bf16, lora_left [K,r], lora_right [r,N],
-    scaling_factor (1,1) of the second quantisation, error_mat fp32, rank)."""
+def add_lora(W, W_mask, scaler_row, rank_ratio, num_bits=4, tile=None, slim_lora=True, quantize=True,
+             scale_important_weights=False, slim_quant=True, block=None, quantize_first=True):
+    """slim/lora.py:105-213, branch separate_lora=True, no prune_lora.  block: the tiled group quantiser with
+    that tile instead of the per-tensor one.  Returns dict(weight bf16, lora_left [K,r], lora_right [r,N],
+    scaling_factor (1,1) of the second quantisation (None when tiled), error_mat fp32, rank)."""
     use_slim = slim_lora and not bool((scaler_row == 0).any())
     sf = None
+    important = important_columns(W, scaler_row) if scale_important_weights else None
+
+    def fake_quant(x):
+        if block is not None:
+            return group_fake_quantize(x, block, num_bits, important)[0], None
+        codes, sf_ = quantize_per_tensor(x, num_bits, slim_quant=slim_quant, important=important)
+        return dequantize_per_tensor(codes, sf_, important), sf_
+
     if use_slim:
         s = torch.sqrt(scaler_row.reshape((1, -1)))
         W_metric = W * s
         if quantize:
-            codes, sf = quantize_per_tensor(W, num_bits)
-            new_w = dequantize_per_tensor(codes, sf) * s
+            src = W if quantize_first else W.masked_fill(W_mask, 0)
+            new_w, sf = fake_quant(src)
+            new_w = new_w * s
         else:
             new_w = W_metric.clone()
         new_w[W_mask] = 0
@@ -267,8 +309,7 @@ def add_lora(W, W_mask, scaler_row, rank_ratio, num_bits=4, tile=None, slim_lora
     else:
         new_w = W.clone()
         if quantize:
-            codes, sf = quantize_per_tensor(new_w, num_bits)
-            new_w = dequantize_per_tensor(codes, sf)
+            new_w, sf = fake_quant(new_w)
         new_w[W_mask] = 0
         error_mat = W - new_w
     U, S, V = torch.svd(error_mat.float())
@@ -282,8 +323,7 @@ def add_lora(W, W_mask, scaler_row, rank_ratio, num_bits=4, tile=None, slim_lora
     new_w = W - low_rank
     new_w[W_mask] = 0
     if quantize:
-        codes, sf = quantize_per_tensor(new_w, num_bits)
-        new_w = dequantize_per_tensor(codes, sf)
+        new_w, sf = fake_quant(new_w)
     return dict(weight=new_w.to(torch.bfloat16).contiguous(), lora_left=L.to(torch.bfloat16).contiguous(),
                 lora_right=R.to(torch.bfloat16).contiguous(), scaling_factor=sf, error_mat=error_mat.float(),
                 rank=rank, singular_values=S)

@@ -42,6 +42,12 @@ PROTOTYPES = {
     "slim_fake_quant_pt": (i32, [vp, i64, vp, i32, vp, vp, vp]),
     "slim_error_matrix": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
     "slim_error_matrix_deq": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp]),
+    "slim_important_columns_workspace_bytes": (i64, [i64, i64]),
+    "slim_important_columns": (i32, [vp, vp, i64, i64, i64, vp, vp, i64, vp]),
+    "slim_scale_columns_bf16": (i32, [vp, vp, i64, i64, f32, vp, vp]),
+    "slim_scale_columns_f32": (i32, [vp, vp, i64, i64, f32, vp]),
+    "slim_error_matrix_cols": (i32, [vp, vp, vp, vp, i32, vp, i32, i64, i64, vp, vp, vp]),
+    "slim_error_matrix_t_rounded": (i32, [vp, vp, vp, vp, i32, i32, i64, i64, vp, vp, vp]),
     "slim_transpose_bf16": (i32, [vp, i64, i64, vp, vp]),
     "slim_gemm_nt_bf16": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, f32, vp, i64, vp, i64, vp, i64, vp]),
     "slim_lora_prune_workspace_bytes": (i64, [i64, i64, i64]),

@@ -35,9 +35,13 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    shared = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "slim_hip.h"), __file__]
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
+        # an object newer than its source and every shared header is kept (force: everything is recompiled)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) < os.path.getmtime(obj) for d in [src] + shared):
+            continue
         cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -1369,7 +1369,9 @@ extern "C" int slim_lora_prepare(const void* W, const float* scaler_row, int64_t
         if (quant_mode == 1) CHK(slim_quant_search(hist, (int)bins, num_bits, alpha, nullptr, sf_out, search_ws, search_bytes, stream));
         else CHK(slim_absmax_scale(hist, num_bits, alpha, sf_out, stream));
     }
-    CHK(slim_error_matrix_t(W, mask, scale_error ? s_out : nullptr, quant_mode ? sf_out : nullptr, num_bits, N, K, E, Et, stream));
+    // (the abs-max quantiser's scale is a bf16 tensor in the reference, so its dequantised values are bf16)
+    CHK(slim_error_matrix_t_rounded(W, mask, scale_error ? s_out : nullptr, quant_mode ? sf_out : nullptr, num_bits, quant_mode == 2, N, K,
+                                    E, Et, stream));
     if (t == 0) return SLIM_OK;
     CHK(slim_outlier_basis(Et, N, outlier_idx, t, tp, UO, UOt, basis_ws, slim_outlier_basis_workspace_bytes(tp), stream));
     CHK(slim_outlier_project(Et, UOt, K, N, tp, Ct, stream));

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restr
                                                            const float* __restrict__ s, const float* __restrict__ sf_p,
                                                            int num_bits, int64_t N, int64_t K,
                                                            float* __restrict__ e32, bf16_t* __restrict__ e16,
-                                                           const bf16_t* __restrict__ wdeq) {
+                                                           const bf16_t* __restrict__ wdeq,
+                                                           const uint8_t* __restrict__ colflags, int deq_bf16) {
     const float sf = sf_p ? sf_p[0] : 0.f;
     const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
     const int64_t cpr = K >> 3, total = N * cpr;
@@ -521,6 +522,8 @@ __global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restr
         const uint2 mk = *(const uint2*)(mask + off);
         u16x8 xd = x;
         if (wdeq) xd = *(const u16x8*)(wdeq + off);
+        uint2 cf = uint2{0u, 0u};
+        if (colflags) cf = *(const uint2*)(colflags + c0);
         float sv[8];
         if (s) {
             const f32x4 a = *(const f32x4*)(s + c0), b = *(const f32x4*)(s + c0 + 4);
@@ -542,8 +545,15 @@ __global__ __launch_bounds__(256) void error_matrix_kernel(const bf16_t* __restr
             float nw;
             if (pruned) nw = 0.f;
             else if (wdeq) nw = bf16_to_f32(xd[j]) * sv[j];
-            else if (sf_p) nw = (quant_code(x[j], sf, qmin, qmax) / sf) * sv[j];
-            else nw = metric;
+            else if (sf_p) {
+                // flagged columns (quantization.py:160-170): the code of the doubled weight, the dequantised value halved
+                // a bf16 scale (abs-max, quantization.py:190-194) makes `codes / scale` a bf16 tensor (:212)
+                const bool scaled = ((j < 4 ? cf.x >> (8 * j) : cf.y >> (8 * (j - 4))) & 0xffu) != 0;
+                float dq = quant_code(scaled ? f32_to_bf16(wf * 2.f) : x[j], sf, qmin, qmax) / sf;
+                if (deq_bf16) dq = round_bf16(dq);
+                if (scaled) dq *= 0.5f;
+                nw = dq * sv[j];
+            } else nw = metric;
             e[j] = metric - nw;
         }
         if (e32) {
@@ -568,7 +578,26 @@ extern "C" int slim_error_matrix(const void* W, const uint8_t* mask, const float
     int64_t blocks = ceil_div64(N * (K >> 3), 256);
     blocks = blocks > 8192 ? 8192 : blocks;
     error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K,
-                                                                          E_f32, (bf16_t*)E_bf16, nullptr);
+                                                                          E_f32, (bf16_t*)E_bf16, nullptr, nullptr, 0);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// slim_error_matrix in its general form.  col_flags (may be NULL): col_flags[c] != 0 marks the input channels whose
+// weights are quantised at twice their size and halved after dequantisation (scale_important_weights).  deq_bf16: the
+// dequantised value code / sf is rounded to bf16 before it meets s (what the reference's abs-max quantiser, whose scale is
+// a bf16 tensor, leaves; SLiM-Quant scales are fp32 and leave fp32 values).
+extern "C" int slim_error_matrix_cols(const void* W, const uint8_t* mask, const float* s, const float* sf, int num_bits,
+                                      const uint8_t* col_flags, int deq_bf16, int64_t N, int64_t K, float* E_f32, void* E_bf16,
+                                      void* stream) {
+    SLIM_REQUIRE(W && mask && sf && (E_f32 || E_bf16) && N > 0 && K > 0, "slim_error_matrix_cols: bad arguments");
+    SLIM_REQUIRE(K % 8 == 0 && ((uintptr_t)col_flags % 8) == 0, "slim_error_matrix_cols: K must be a multiple of 8");
+    SLIM_REQUIRE(num_bits >= 2 && num_bits <= 8, "slim_error_matrix_cols: num_bits must be in [2, 8]");
+    SLIM_PROF("error_matrix", stream, (3.0 + (E_f32 ? 4.0 : 0.0) + (E_bf16 ? 2.0 : 0.0)) * N * K);
+    int64_t blocks = ceil_div64(N * (K >> 3), 256);
+    blocks = blocks > 8192 ? 8192 : blocks;
+    error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K,
+                                                                          E_f32, (bf16_t*)E_bf16, nullptr, col_flags, deq_bf16);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
@@ -579,7 +608,7 @@ extern "C" int slim_error_matrix(const void* W, const uint8_t* mask, const float
 __global__ __launch_bounds__(256) void error_matrix_t_kernel(const bf16_t* __restrict__ w, const uint8_t* __restrict__ mask,
                                                              const float* __restrict__ s, const float* __restrict__ sf_p,
                                                              int num_bits, int64_t N, int64_t K, bf16_t* __restrict__ e16,
-                                                             bf16_t* __restrict__ et16) {
+                                                             bf16_t* __restrict__ et16, int deq_bf16) {
     __shared__ bf16_t tile[64][72];      // row stride 144 bytes: 16-byte rows for the vector stores, odd multiple of 16 bytes
     const float sf = sf_p ? sf_p[0] : 0.f;
     const float qmax = (float)((1 << (num_bits - 1)) - 1), qmin = -qmax - 1.f;
@@ -613,8 +642,11 @@ __global__ __launch_bounds__(256) void error_matrix_t_kernel(const bf16_t* __res
                 const bool pruned = ((j < 4 ? mk.x >> (8 * j) : mk.y >> (8 * (j - 4))) & 0xffu) != 0;
                 float nw;
                 if (pruned) nw = 0.f;
-                else if (sf_p) nw = (quant_code(x[j], sf, qmin, qmax) / sf) * sv[j];
-                else nw = metric;
+                else if (sf_p) {
+                    float dq = quant_code(x[j], sf, qmin, qmax) / sf;
+                    if (deq_bf16) dq = round_bf16(dq);
+                    nw = dq * sv[j];
+                } else nw = metric;
                 o[j] = f32_to_bf16(metric - nw);
             }
             *(u16x8*)(e16 + off) = o;
@@ -636,6 +668,11 @@ __global__ __launch_bounds__(256) void error_matrix_t_kernel(const bf16_t* __res
 
 extern "C" int slim_error_matrix_t(const void* W, const uint8_t* mask, const float* s, const float* sf, int num_bits, int64_t N,
                                    int64_t K, void* E_bf16, void* Et_bf16, void* stream) {
+    return slim_error_matrix_t_rounded(W, mask, s, sf, num_bits, 0, N, K, E_bf16, Et_bf16, stream);
+}
+
+extern "C" int slim_error_matrix_t_rounded(const void* W, const uint8_t* mask, const float* s, const float* sf, int num_bits,
+                                           int deq_bf16, int64_t N, int64_t K, void* E_bf16, void* Et_bf16, void* stream) {
     SLIM_REQUIRE(W && mask && E_bf16 && Et_bf16 && N > 0 && K > 0, "slim_error_matrix_t: bad arguments");
     SLIM_REQUIRE(K % 8 == 0 && N % 8 == 0, "slim_error_matrix_t: N and K must be multiples of 8");
     SLIM_REQUIRE(!sf || (num_bits >= 2 && num_bits <= 8), "slim_error_matrix_t: num_bits must be in [2, 8]");
@@ -643,7 +680,7 @@ extern "C" int slim_error_matrix_t(const void* W, const uint8_t* mask, const flo
     SLIM_PROF("error_matrix", stream, 7.0 * N * K);
     dim3 grid((unsigned)ceil_div64(K, 64), (unsigned)ceil_div64(N, 64));
     error_matrix_t_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, sf, num_bits, N, K, (bf16_t*)E_bf16,
-                                                                 (bf16_t*)Et_bf16);
+                                                                 (bf16_t*)Et_bf16, deq_bf16);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }
@@ -658,7 +695,7 @@ extern "C" int slim_error_matrix_deq(const void* W, const void* Wdeq, const uint
     int64_t blocks = ceil_div64(N * (K >> 3), 256);
     blocks = blocks > 8192 ? 8192 : blocks;
     error_matrix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, mask, s, nullptr, 4, N, K, E_f32,
-                                                                          (bf16_t*)E_bf16, (const bf16_t*)Wdeq);
+                                                                          (bf16_t*)E_bf16, (const bf16_t*)Wdeq, nullptr, 0);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }

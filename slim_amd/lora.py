@@ -346,8 +346,6 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     """First phase of add_lora (lora.py:105-169): argument checks, first quantisation, error matrix E (and its
     transpose) -- written into E_out / Et_out when given, so that same-shape layers of a block sit in one
     strided buffer for the batched fit."""
-    if scale_important_weights:
-        raise NotImplementedError("scale_important_weights is not implemented")
     if prune_lora and not separate_lora:
         raise NotImplementedError("prune_lora needs separate adapters")          # lora.py:190-191
     W = module.weight.data
@@ -358,6 +356,8 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     c.prune_lora, c.lora_left_mask = bool(prune_lora), None
     c.W = W.contiguous()
     N, K = c.W.shape
+    # lora.py:132-138: the 1 % of input channels with the largest scaler_row * sum |W| are quantised at twice their size
+    c.important = ops.important_columns(c.W, activations.scaler_row) if (scale_important_weights and quantizer is not None) else None
     c.bits = quantizer.num_bits if quantizer is not None else 4
     has_zero = getattr(activations, "has_zero", None)       # precomputed by the driver (one sync per block)
     if has_zero is None:
@@ -371,14 +371,17 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
     if quantizer is not None and not quantize_first:
         Wq_src = c.W.clone()
         Wq_src[W_mask] = 0
+    # the one first quantisation that ignores the important columns: naive branch, mask first (lora.py:167)
+    imp_first = c.important if (use_slim or quantize_first) else None
     if quantizer is not None and quantizer.block_quantization:
         # tiled group quantiser (quantization.py:139-148): its dequantised values are a bf16 tensor
-        Wdeq = _tiled_fake_quant(Wq_src, quantizer)
+        Wdeq = _tiled_fake_quant(Wq_src, quantizer, imp_first)
         c.E = ops.error_matrix_deq(c.W, Wdeq, W_mask, c.s, out=E_out)
         del Wdeq
     else:
         sf1 = _weight_scale(Wq_src, quantizer).reshape(1) if quantizer is not None else None
-        _, c.E = ops.error_matrix(c.W, W_mask, c.s, sf1, c.bits, out=E_out)
+        _, c.E = ops.error_matrix(c.W, W_mask, c.s, sf1, c.bits, out=E_out, col_flags=imp_first,
+                                  deq_bf16=quantizer is not None and not quantizer.slim_quant)
     c.Et = ops.transpose(c.E, out=Et_out)
 
     rank = lora_rank((N, K), rank_ratio, lora_tile_size)
@@ -533,7 +536,8 @@ def add_lora_finish(c, prescale=False):
     c.touch()
     U, lora_right, lora_left, fit_info = c.fit
     module, quantizer, rank = c.module, c.quantizer, c.rank
-    if c.separate and c.lora_left_mask is None and (quantizer is None or not quantizer.block_quantization):
+    important = getattr(c, "important", None)
+    if c.separate and c.lora_left_mask is None and (quantizer is None or not quantizer.block_quantization) and important is None:
         # separate adapters, per-tensor quantiser or none: the whole tail is one library call
         mode = 0 if quantizer is None else (1 if quantizer.slim_quant else 2)
         new_weight, sf, left, right = ops.lora_finish(U, lora_left, c.W, c.W_mask, rank, mode, c.bits, prescale)
@@ -558,14 +562,7 @@ def add_lora_finish(c, prescale=False):
             low_rank_weight /= c.s.reshape(1, -1).to(torch.bfloat16)
         new_weight = c.W - low_rank_weight
         new_weight[c.W_mask] = 0
-    sf_out = None
-    if quantizer is not None and quantizer.block_quantization:
-        new_weight = _tiled_fake_quant(new_weight, quantizer)
-    elif quantizer is not None:
-        sf2 = _weight_scale(new_weight, quantizer)
-        new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), c.bits)
-        sf_out = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
-        quantizer.scaling_factor = sf_out
+    new_weight, sf_out = requantize_weight(new_weight, quantizer, c.bits, important)
     module.lora_fit_info = fit_info
     if not c.separate:
         # lora.py:213: the adapters are folded back into the (then dense) weight
@@ -591,8 +588,7 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     (lora.py:105-213).  Sets module.lora_left [K, r], module.lora_right [r, N] and module.weight.data.
 
     Implemented: quantizer None, per-tensor (SLiM-Quant / abs-max) or tiled group abs-max, slim_lora on or off,
-    quantize_first either way, adapters kept separate or merged back.  scale_important_weights and prune_lora
-    raise NotImplementedError.
+    quantize_first either way, adapters kept separate, merged back or pruned, scale_important_weights.
     The driver runs the three phases separately so that same-shape layers share one batched fit.
     """
     c = add_lora_prepare(module, W_mask, rank_ratio, slim_lora, activations, quantizer, prune_lora, separate_lora,
@@ -601,14 +597,43 @@ def add_lora(module, W_mask, rank_ratio=0.01, slim_lora=False, activations=None,
     add_lora_finish(c)
 
 
-def _tiled_fake_quant(W, quantizer):
+def requantize_weight(new_weight, quantizer, bits, important=None):
+    """The second quantisation of add_lora (lora.py:202-204): (deq(quant(new_weight)) in bf16, the scaling factor (1, 1) or
+    None), which is also left in quantizer.scaling_factor like the reference does.  important: bool [K] flags of the
+    columns quantised at twice their size (scale_important_weights), or None."""
+    if quantizer is None:
+        return new_weight, None
+    if quantizer.block_quantization:
+        return _tiled_fake_quant(new_weight, quantizer, important), None
+    sf2 = _weight_scale(new_weight, quantizer)             # the threshold comes from the unscaled weight (:184-192)
+    if important is not None:
+        # codes of the doubled columns, dequantised values halved (quantization.py:192, :215): a power of two commutes
+        # with the rounding to bf16
+        new_weight = ops.fake_quant_pt(ops.scale_columns(new_weight, important, 2.0), sf2.reshape(1), bits)
+        ops.scale_columns(new_weight, important, 0.5, out=new_weight)
+    else:
+        new_weight = ops.fake_quant_pt(new_weight, sf2.reshape(1), bits)
+    sf_out = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
+    quantizer.scaling_factor = sf_out
+    return new_weight, sf_out
+
+
+def _tiled_fake_quant(W, quantizer, important=None):
     """deq(quant(W)) under the tiled group quantiser (Quantizer.quantize_weight block branch + dequantize_absmax,
-    quantization.py:139-148, :203-217) without touching the quantizer's state: layers are compressed concurrently."""
+    quantization.py:139-148, :203-217) without touching the quantizer's state: layers are compressed concurrently.
+    important (bool [K] or None): those columns are doubled after the group scales have been taken and halved after
+    dequantisation (:146-148, :215)."""
     assert W.shape[0] % quantizer.block_dim == 0 and W.shape[1] % quantizer.block_dim == 0, \
         "Input matrix size is not divisible by block size"
     if quantizer.slim_quant:
         raise NotImplementedError("SLiM-Quant is not supported for block quantization")
-    return ops.group_fake_quant(W.contiguous(), quantizer.block_dim, quantizer.num_bits)
+    if important is None:
+        return ops.group_fake_quant(W.contiguous(), quantizer.block_dim, quantizer.num_bits)
+    W = W.contiguous()
+    alphas = ops.group_absmax(W, quantizer.block_dim)
+    codes = ops.group_quantize(ops.scale_columns(W, important, 2.0), alphas, quantizer.num_bits)
+    deq = ops.group_dequantize(codes, alphas, quantizer.num_bits)
+    return ops.scale_columns(deq, important, 0.5, out=deq)
 
 
 def _weight_scale(W, quantizer):

@@ -216,14 +216,59 @@ def _out_or_new(out, shape, device, name):
     return out
 
 
-def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=None):
+def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=None, col_flags=None, deq_bf16=False):
+    """(E fp32 or None, E bf16 or None), E = W * s - mask0((code / sf) * s) (sf None: no quantiser).
+    col_flags (bool [K]): columns quantised at twice their size and halved after dequantisation (scale_important_weights).
+    deq_bf16: code / sf rounded to bf16 first (the abs-max quantiser, whose scale is a bf16 tensor in the reference)."""
     W = _chk(W, BF16, "W")
     mask = _chk(mask, torch.bool, "mask")
     N, K = W.shape
     e32 = torch.empty(N, K, dtype=torch.float32, device=W.device) if want_f32 else None
     e16 = _out_or_new(out, (N, K), W.device, "error_matrix") if want_bf16 else None
-    _lib.call("slim_error_matrix", _p(W), _p(mask), _p(s), _p(sf), num_bits, N, K, _p(e32), _p(e16), _stream())
+    if sf is not None and (col_flags is not None or deq_bf16):
+        if col_flags is not None:
+            col_flags = _chk(col_flags, torch.bool, "col_flags")
+        _lib.call("slim_error_matrix_cols", _p(W), _p(mask), _p(s), _p(sf), num_bits, _p(col_flags), int(bool(deq_bf16)), N, K,
+                  _p(e32), _p(e16), _stream())
+    else:
+        _lib.call("slim_error_matrix", _p(W), _p(mask), _p(s), _p(sf), num_bits, N, K, _p(e32), _p(e16), _stream())
     return e32, e16
+
+
+def important_columns(W, scaler_row, count=None):
+    """Flags (bool [K], True = important) of the `count` input channels with the largest
+    scaler_row * bf16(column sums of |W|); count defaults to int(0.01 * K) (slim/lora.py:132-136)."""
+    W = _chk(W, BF16, "W")
+    scaler_row = _chk(scaler_row, torch.float32, "scaler_row")
+    N, K = W.shape
+    assert scaler_row.numel() == K
+    if count is None:
+        count = int(0.01 * K)
+    flags = torch.empty(K, dtype=torch.bool, device=W.device)
+    ws = _ws(_lib.query("slim_important_columns_workspace_bytes", N, K), W.device)
+    _lib.call("slim_important_columns", _p(W), _p(scaler_row), N, K, int(count), _p(flags), _p(ws), ws.numel(), _stream())
+    return flags
+
+
+def scale_columns(x, flags, factor, out=None):
+    """bf16(x * factor) in the flagged columns of x [N, K], x elsewhere; out may be x itself."""
+    x = _chk(x, BF16, "x")
+    flags = _chk(flags, torch.bool, "flags")
+    N, K = x.shape
+    assert flags.numel() == K
+    out = torch.empty_like(x) if out is None else _out_or_new(out, (N, K), x.device, "scale_columns")
+    _lib.call("slim_scale_columns_bf16", _p(x), _p(flags), N, K, float(factor), _p(out), _stream())
+    return out
+
+
+def scale_columns_f32_(x, flags, factor):
+    """x [N, K] fp32 times factor in the flagged columns, in place."""
+    _chk(x, torch.float32, "x")
+    if not x.is_contiguous():
+        raise ValueError("scale_columns_f32_: x must be contiguous")
+    flags = _chk(flags, torch.bool, "flags")
+    _lib.call("slim_scale_columns_f32", _p(x), _p(flags), x.shape[0], x.shape[1], float(factor), _stream())
+    return x
 
 
 def error_matrix_deq(W, Wdeq, mask, s, out=None):

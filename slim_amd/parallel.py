@@ -65,6 +65,11 @@ def all_reduce(t, group=None, op="sum"):
     return t
 
 
+def all_reduce_max(t, group=None):
+    """all_reduce with MAX (status words: every rank sees the worst)."""
+    return all_reduce(t, group, op="max")
+
+
 def reduce(t, dst, group=None):
     """In place sum onto rank dst (the other ranks' tensors are left undefined)."""
     if _alone(group):

@@ -444,10 +444,14 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
             if describe:
                 describe(name)
             W_mask = mask_of(lin, wrapped)
+            important = None
+            if scale_important_weights:
+                # prune.py:331-335 reads `scaler_row` off the nn.Linear, which has none: the reference raises here
+                important = ops.important_columns(lin.weight.data, lin.scaler_row)
             # prune.py:330-357: quantise the dense weight then zero the mask, or the other way round
             def quantise():
                 if quantizer is not None:
-                    codes = quantizer.quantize_weight(lin.weight.data)
+                    codes = quantizer.quantize_weight(lin.weight.data, important)
                     lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
                     lin.scaling_factor = None if tiled_weight_quantization else quantizer.scaling_factor
             if quantize_first:
@@ -640,11 +644,19 @@ def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora
                     lin.scaling_factor = torch.empty(1, 1, dtype=scale_dtype, device=dev)
                 parallel.broadcast(lin.scaling_factor, owner[j])
     # the owners' packing status words, read with one synchronisation
-    pending = [(n, subset[n].__dict__.pop("pack_status")) for n in names if "pack_status" in subset[n].__dict__]
-    if pending:
-        for (n, _), st in zip(pending, torch.cat([p for _, p in pending]).cpu().tolist()):
-            if st:
-                raise ValueError(f"{n}: the compressed weight does not have the packed 2:4 int4 form (status {st})")
+    # the owners' packing status words, one per linear (0 where nothing was packed), combined over the ranks so that every
+    # rank raises together: the receivers have unpacked what the owner sent and would otherwise run on into the next
+    # block's collectives
+    words = torch.zeros(len(names), dtype=torch.int32, device=dev)
+    for j, n in enumerate(names):
+        st = subset[n].__dict__.pop("pack_status", None)
+        if st is not None:
+            words[j] = st.reshape(-1)[0].to(torch.int32)
+    words = parallel.all_reduce_max(words).cpu().tolist()
+    bad = [(n, st) for n, st in zip(names, words) if st]
+    if bad:
+        raise ValueError("; ".join(f"{n}: the compressed weight does not have the packed 2:4 int4 form (status {st})"
+                                   for n, st in bad))
 
 
 def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quantize_weight=False, bitwidth=4,
@@ -653,8 +665,6 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                 separate_lora=True, nsamples=128, seed=0, calibration_dataset="c4", pad_lora=False,
                 quantize_first=True, scale_important_weights=False):
     """Wanda N:M pruning + weight quantisation + low-rank adapters, block by block (prune.py:148-372)."""
-    if scale_important_weights:
-        raise NotImplementedError("scale_important_weights is not implemented")
     dev = _device()
     use_cache = model.config.use_cache
     model.config.use_cache = False
@@ -714,8 +724,10 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                     callback=(lambda name, lin, wrapped, i=i: LAYER_CALLBACK(i, name, lin, wrapped)) if LAYER_CALLBACK else None,
                     describe=lambda name, i=i: progress_bar.set_description(f"Layer {i} - Pruning and Quantizing {name}"))
         everything = [(n, subset[n], wrapped_layers[n]) for n in names]
+        # a precomputed mask need not be 2:4, and important columns carry levels of half the size: neither has the packed form
+        given_masks = any(hasattr(subset[n].weight, "mask") for n in names)
         from . import sharded
-        if world > 1 and SHARD_LINEARS and sharded.supported(everything, world, prune_n, prune_m, quantizer, lora_rank, slim_lora,
+        if world > 1 and SHARD_LINEARS and not scale_important_weights and sharded.supported(everything, world, prune_n, prune_m, quantizer, lora_rank, slim_lora,
                                                              prune_lora, separate_lora, quantize_first, tile_rule):
             # every linear cut into blocks over all ranks; every rank ends with the whole compressed block
             compress_linears(everything, dev, prune_n, prune_m, shard=True, **opts)
@@ -727,7 +739,8 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
                 _exchange_block(names, subset, owner, rank, dev, lora_rank, quantize_lora or pad_lora, lora_tile_size,
                                 quantizer is not None and not tiled_weight_quantization, separate_lora,
                                 torch.float32 if slim_quant else torch.bfloat16, prune_lora,
-                                (prune_n, prune_m, bitwidth if (quantizer is not None and quantize_first) else 0))
+                                (prune_n, prune_m, bitwidth if (quantizer is not None and quantize_first and not given_masks
+                                                                and not scale_important_weights) else 0))
 
         if i + 1 < len(layers):         # (the last block's outputs feed nothing)
             progress_bar.set_description(f"Layer {i} - Evaluating Output")

@@ -45,10 +45,12 @@ class Quantizer:
 
     def quantize_weight(self, mat, important_columns=None):
         """quantization.py:133-157.  Group branch: one bf16 scale per (block_dim rows x 1 column).
-        Per-tensor branch: SLiM-Quant (histogram search) or abs-max scale, int8 codes."""
-        if important_columns is not None:
-            raise NotImplementedError("scale_important_weights is not implemented")
-        self.important_columns = None
+        Per-tensor branch: SLiM-Quant (histogram search) or abs-max scale, int8 codes.
+        important_columns (index tensor, or a bool [K] tensor of flags): the scale(s) come from `mat` as it is, the
+        codes from `mat` with those columns divided by important_columns_scaling_factor (:147, :192); dequantize_absmax
+        multiplies them back (:215).  The reference scales `mat` in place and undoes it (:156); here `mat` is not
+        touched."""
+        self.important_columns = self._column_flags(mat, important_columns)
         if self.num_bits > 8:
             raise NotImplementedError("weight quantisation above 8 bits is not implemented")
         if self.block_quantization:
@@ -58,10 +60,26 @@ class Quantizer:
                 raise NotImplementedError("SLiM-Quant is not supported for block quantization")
             self.dtype = mat.dtype
             self.scaling_factor, _ = compute_quantization_params(mat, self.block_dim, 1, symmetric=True)
-            return quantize_tensor(mat, self.scaling_factor, None, self.num_bits)
+            return quantize_tensor(self._scaled(mat), self.scaling_factor, None, self.num_bits)
         quantized_mat, scaling_factor = self.quantize_block(mat, self.num_bits, self.slim_quant)
         self.scaling_factor = scaling_factor.reshape(1, 1)
         return quantized_mat
+
+    @staticmethod
+    def _column_flags(mat, important_columns):
+        if important_columns is None:
+            return None
+        if important_columns.dtype == torch.bool:
+            return important_columns.to(mat.device)
+        flags = torch.zeros(mat.shape[1], dtype=torch.bool, device=mat.device)
+        flags[important_columns.to(mat.device).long()] = True
+        return flags
+
+    def _scaled(self, mat):
+        """`mat` with the important columns divided by their factor (quantization.py:168), a copy."""
+        if getattr(self, "important_columns", None) is None:
+            return mat
+        return ops.scale_columns(mat, self.important_columns, 1.0 / self.important_columns_scaling_factor)
 
     def quantize_block(self, mat, num_bits=8, slim_quant=False, important_columns=None):
         """quantization.py:173-200: (int8 codes, 0-d scaling factor maxq / alpha)."""
@@ -73,7 +91,7 @@ class Quantizer:
             _, _, sf, _ = ops.quant_search(hist, bins, num_bits)
         else:
             _, sf = ops.absmax_scale(hist, num_bits)
-        codes = ops.quantize_pt(mat, sf.reshape(1), num_bits)
+        codes = ops.quantize_pt(self._scaled(mat), sf.reshape(1), num_bits)
         # abs-max scales are bf16 in the reference (bf16 max -> bf16 quotient); SLiM-Quant scales are fp32
         return codes, (sf if slim_quant else sf.to(torch.bfloat16))
 
@@ -81,10 +99,21 @@ class Quantizer:
         """quantization.py:203-217."""
         if scaling_factor is None:
             scaling_factor = self.scaling_factor
+        flags = getattr(self, "important_columns", None)
         if scaling_factor.shape == (1, 1):
             as_bf16 = scaling_factor.dtype == torch.bfloat16
-            return ops.dequantize_pt(quantized_mat, scaling_factor.float().reshape(1), out_bf16=as_bf16)
-        return dequantize_tensor(quantized_mat, scaling_factor, None, self.num_bits, dtype=self.dtype)
+            deq = ops.dequantize_pt(quantized_mat, scaling_factor.float().reshape(1), out_bf16=as_bf16)
+            if flags is not None:
+                # deq_mat[:, cols] *= 1/2 (:215): exact in either dtype
+                if as_bf16:
+                    ops.scale_columns(deq, flags, self.important_columns_scaling_factor, out=deq)
+                else:
+                    ops.scale_columns_f32_(deq, flags, self.important_columns_scaling_factor)
+            return deq
+        deq = dequantize_tensor(quantized_mat, scaling_factor, None, self.num_bits, dtype=self.dtype)
+        if flags is not None:
+            ops.scale_columns(deq, flags, self.important_columns_scaling_factor, out=deq)
+        return deq
 
     def quantize_input(self, mat):
         """quantization.py:219-251 fused with dequantize_input :253-263: returns the DEQUANTISED

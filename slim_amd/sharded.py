@@ -180,7 +180,7 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         ops.hist_abs(j.W_s, hist)
         parallel.all_reduce(hist, group)
         sf1 = _scale(hist, N * K, quantizer)
-        _, j.E_s = ops.error_matrix(j.W_s, j.mask_s, j.s_s, sf1.reshape(1), j.bits)
+        _, j.E_s = ops.error_matrix(j.W_s, j.mask_s, j.s_s, sf1.reshape(1), j.bits, deq_bf16=not quantizer.slim_quant)
         j.Et_s = ops.transpose(j.E_s)
         j.defl_rows = j.defl_dm = j.info_o = None
         if j.t:

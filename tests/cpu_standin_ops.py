@@ -63,10 +63,14 @@ def fake_quant_pt(W, sf, num_bits, want_codes=False):
     return (_codes(W, sf, num_bits) / sf.reshape(())).to(BF16)
 
 
-def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=None):
+def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=None, col_flags=None, deq_bf16=False):
     """slim/lora.py:146-156: E = W s - mask0(deq(q(W)) s)."""
+    assert col_flags is None
     sc = s.reshape(1, -1) if s is not None else 1.0
-    new_w = _codes(W, sf, num_bits) / sf.reshape(()) * sc
+    deq = _codes(W, sf, num_bits) / sf.reshape(())
+    if deq_bf16:
+        deq = deq.to(BF16).float()
+    new_w = deq * sc
     new_w[mask] = 0
     E = W * sc - new_w
     return (E.float() if want_f32 else None), E.to(BF16)

@@ -149,3 +149,55 @@ def test_g13_oracle_reproduces_reference_end_to_end_layers(golden, tag):
             sq = torch.sqrt(torch.tensor(r))
             assert torch.equal(out["lora_left"] * sq, g8[p + "lora_left"]), p
             assert torch.equal(out["lora_right"] * sq, g8[p + "lora_right"]), p
+
+
+# ---- scale_important_weights (g15: the reference's add_lora with its error matrix recorded) ------------------------
+@pytest.mark.parametrize("tag", ["slim", "slim_tall", "absmax", "slim_maskfirst"])
+def test_important_columns_per_tensor(golden, tag):
+    g = golden("g15_important")
+    p = tag + "/"
+    W, sr, mask = g[p + "W"], g[p + "scaler_row"], g[p + "mask"].bool()
+    qf = bool(int(g[p + "quantize_first"]))
+    imp = O.important_columns(W, sr)
+    assert torch.equal(torch.sort(imp)[0], g[p + "important"])
+    assert torch.equal(W.abs().sum(dim=0), g[p + "colsum"])
+    slim_quant = tag != "absmax"
+    src = W if qf else W.masked_fill(mask, 0)
+    codes, sf = O.quantize_per_tensor(src, 4, slim_quant=slim_quant, important=imp)
+    assert torch.equal(codes, g[p + "codes1"])
+    assert torch.equal(sf.float(), g[p + "sf1"])
+    assert torch.equal(O.dequantize_per_tensor(codes, sf, imp), g[p + "deq1"])
+    out = O.add_lora(W, mask, sr, 0.1, num_bits=4, tile=None, scale_important_weights=True, slim_quant=slim_quant,
+                     quantize_first=qf)
+    assert torch.equal(out["error_mat"], g[p + "E"])
+    # the important columns carry levels of half the size: up to 32 distinct values in the weight instead of 16
+    assert torch.equal(out["weight"], g[p + "weight"])
+    assert torch.equal(out["scaling_factor"].float(), g[p + "sf2"])
+    assert torch.equal(out["lora_left"], g[p + "lora_left"]) and torch.equal(out["lora_right"], g[p + "lora_right"])
+    assert torch.unique(out["weight"][:, imp]).numel() <= 16
+    assert torch.unique(out["weight"]).numel() <= 32
+
+
+@pytest.mark.parametrize("tag", ["t128", "t128_maskfirst"])
+def test_important_columns_tiled(golden, tag):
+    g = golden("g15_important_tiled")
+    p = tag + "/"
+    W, sr, mask = g[p + "W"], g[p + "scaler_row"], g[p + "mask"].bool()
+    qf = bool(int(g[p + "quantize_first"]))
+    imp = O.important_columns(W, sr)
+    assert torch.equal(torch.sort(imp)[0], g[p + "important"])
+    src = W if qf else W.masked_fill(mask, 0)
+    deq, alphas = O.group_fake_quantize(src, 128, 4, imp)
+    assert torch.equal(alphas, g[p + "sf1"])
+    # the Triton CPU interpreter truncates fp32 -> bf16 where a GPU build rounds to nearest: <= 1 bf16 unit
+    d = (deq.view(torch.int16).int() - g[p + "deq1"].view(torch.int16).int()).abs()
+    assert int(d.max()) <= 1
+    # the error matrix the reference handed to its SVD is exactly W * s - mask0(deq * s) of ITS dequantised values; the
+    # oracle's differs from it only through the interpreter's truncation (a bf16 unit of deq is ~10 % of a quantisation
+    # error, so the matrices agree to ~1 % and not to the bit)
+    s = torch.sqrt(sr.reshape(1, -1))
+    E_ref = W * s - (g[p + "deq1"] * s).masked_fill(mask, 0)
+    assert torch.equal(E_ref, g[p + "E"])
+    out = O.add_lora(W, mask, sr, 0.1, num_bits=4, tile=None, scale_important_weights=True, block=128, quantize_first=qf)
+    rel = (torch.norm(out["error_mat"] - g[p + "E"]) / torch.norm(g[p + "E"])).item()
+    assert rel < 2e-2, rel
