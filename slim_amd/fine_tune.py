@@ -76,15 +76,17 @@ def disable_linear_layer_grads(model):
 
 def requantize(model, q=4):
     """fine_tune.py:51-67: weights that were trained (modules without adapters) go back to their grid,
-    round(w * scaling_factor) / scaling_factor in fp32, without clamping (`q` is unused there too).  A one-off elementwise
-    pass in torch on the weight's device."""
+    round((w * scaling_factor).float()) / scaling_factor, without clamping (`q` is unused there too).  The product keeps the
+    dtype torch's promotion gives it, as in the reference: fp32 with a SLiM-Quant scale (fp32 (1, 1)), but bf16 with an abs-max
+    scale (bf16 (1, 1)) under a bf16 weight -- it is then rounded to bf16 before it is rounded to an integer.  A one-off
+    elementwise pass in torch on the weight's device."""
     for _, module in model.named_modules():
         if type(module).__name__ not in KNOWN_MODULES or hasattr(module, "lora_left") or not hasattr(module, "scaling_factor"):
             continue
         if module.scaling_factor is None:
             raise NotImplementedError("Group quantization is not supported for fine-tuning")
-        sf = module.scaling_factor.to(device=module.weight.device, dtype=torch.float32)
-        w = torch.round(module.weight.data.float() * sf)
+        sf = module.scaling_factor.to(device=module.weight.device)
+        w = torch.round((module.weight.data * sf).float())
         module.weight.data = (w / sf).to(module.weight.dtype)
 
 
@@ -172,9 +174,18 @@ def all_reduce_grads(params, world):
     """Sum the gradients over the ranks and divide by their number: flat buckets of one dtype, one all-reduce each."""
     import torch.distributed as dist
     buckets, size = {}, {}
-    for p in params:
+    params = list(params)
+    # a parameter no rank's batches reached keeps grad None, as on one rank, where the optimizer then skips it (a zero
+    # gradient would still move it on stale momentum): one flag per parameter, summed over the ranks
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device if params else None)
+    if params:
+        dist.all_reduce(has)
+    reached = has.tolist()
+    for p, n in zip(params, reached):
+        if n == 0:
+            continue
         if p.grad is None:
-            p.grad = torch.zeros_like(p)          # a parameter this rank's batches did not reach
+            p.grad = torch.zeros_like(p)          # a parameter this rank's batches did not reach, but another's did
         key = (p.grad.dtype, p.grad.device)
         if size.get(key, 0) + p.grad.numel() * p.grad.element_size() > BUCKET_BYTES and buckets.get(key):
             _reduce_bucket(buckets.pop(key), world, dist)

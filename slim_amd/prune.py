@@ -309,9 +309,11 @@ def gather_block_statistics(layer, subset, wrapped_layers, inps, outs, kwargs, b
             return          # (a linear that ran twice or not at all: keep the plain pass)
         last = first[-1]
 
+        others = set(wrapped_layers) - {last}
+
         def pre(_, args):
             wrapped_layers[last].add_batch(args[0].data, None, per_sample=True)
-            if len(order) == len(wrapped_layers) - 1:      # every other linear has had its input: nothing left to see
+            if set(order) == others:                        # every other linear has had its input: nothing left to see
                 raise _StopBlock
             order.append(last)                              # (a block that changed its order: run on)
 

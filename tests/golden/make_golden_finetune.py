@@ -56,7 +56,15 @@ def build(seed=0):
     d.weight.data = (torch.randn(8, 16, generator=g) * 0.1).to(torch.bfloat16)
     d.weight.data[torch.rand(8, 16, generator=g) < 0.3] = 0
     d.bias.data = d.bias.data.to(torch.bfloat16)
-    for name, mod in zip("abcd", (a, b, c, d)):
+    # no adapters, abs-max style scale: a bf16 (1, 1) tensor, so that `weight * scaling_factor` stays bf16 (requantize then
+    # rounds the product to bf16 before it rounds to an integer); values up to 7 / sf, where bf16 spacing is 2^-5 after scaling
+    e = torch.nn.Linear(16, 16, bias=False)
+    sf16 = torch.tensor([[37.5]], dtype=torch.bfloat16)
+    we = torch.randint(-7, 8, (16, 16), generator=g).float()
+    we[torch.rand(16, 16, generator=g) < 0.5] = 0
+    e.weight.data = (we / sf16.float()).to(torch.bfloat16)
+    e.scaling_factor = sf16
+    for name, mod in zip("abcde", (a, b, c, d, e)):
         m.add_module(name, mod)
     return m, g
 
@@ -79,7 +87,8 @@ def main():
     # dirty what the masking hooks guard (a training step would), then run the pre-hooks the way a forward does
     drift = {}
     for name, mod in m.named_children():
-        drift[name] = (torch.randn(mod.weight.shape, generator=g) * 0.01)
+        # (module e: drifts of the order of half a level, so that products land near the half-way points)
+        drift[name] = (torch.randn(mod.weight.shape, generator=g) * (0.013 if name == "e" else 0.01))
         if not hasattr(mod, "lora_left"):
             mod.weight.data = (mod.weight.data.float() + drift[name]).to(mod.weight.dtype)
         out[f"{name}/drift"] = drift[name].numpy()

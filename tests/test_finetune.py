@@ -139,6 +139,7 @@ if world > 1:
 import slim_amd.fine_tune as F
 from test_finetune import tiny_model, learnable_blocks
 m = tiny_model()
+m.model.never_reached = torch.nn.Parameter(torch.ones(4))     # trainable, in no forward: its grad stays None on every rank
 F.get_token_blocks = lambda *a, **k: (learnable_blocks(32), learnable_blocks(4, seed=4))
 F.LEARNING_RATE = 5e-3
 F.fine_tune(m, None, global_batch_size=int(sys.argv[2]), local_batch_size=1)
@@ -158,6 +159,7 @@ def test_two_ranks_equal_one_rank(tmp_path):
                     "--master-port", "29641", str(worker), ROOT, "4", str(tmp_path / "two")], check=True, env=env, timeout=600)
     one = torch.load(str(tmp_path / "one.0"))
     two = [torch.load(str(tmp_path / f"two.{r}")) for r in range(2)]
+    assert torch.equal(two[0]["model.never_reached"], torch.ones(4))
     for n in one:
         assert torch.equal(two[0][n], two[1][n]), n                       # both ranks hold the same model
         assert float((one[n] - two[0][n]).abs().max()) <= 2e-4 * max(1.0, float(one[n].abs().max())), n
