@@ -88,7 +88,22 @@ def cpu_baseline():
         nbytes += 2.0 * N * K
     dt = sum(times.values())
     block_s = 4 * times["4096x4096"] + 2 * times["11008x4096"] + times["4096x11008"]
+    # the reference's own CPU-runnable case: one decoder block of OPT-125m (4 x 768x768, 3072x768, 768x3072; rank 76 padded to
+    # 256), statistics over 4 of 128 samples of 2048 tokens, every linear of the block; the model has 12 such blocks
+    t0 = time.time()
+    opt_bytes = 0.0
+    for N, K in ((768, 768),) * 4 + ((3072, 768), (768, 3072)):
+        W = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+        X = (torch.randn(4, 2048, K, generator=g) * torch.exp(torch.randn(K, generator=g) * 0.5)).to(torch.bfloat16)
+        sr, n = torch.zeros(K), 0
+        for j in range(4):
+            sr, n = O.add_batch_scaler_row(sr, n, X[j])
+        O.compress_linear(W, sr, rank_ratio=0.1, num_bits=4, tile=256)
+        opt_bytes += 2.0 * N * K
+    opt_s = time.time() - t0
     return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "opt125m": {"block_of_6_linears_s": opt_s, "value": opt_bytes / opt_s / 1e9, "unit": "GB/s",
+                        "model_of_12_blocks_extrapolated_s": 12 * opt_s},
             "sample": "one linear of each distinct shape of the block (4096x4096, 11008x4096, 4096x11008), statistics over 4 of "
                       "128 samples, mask, 2 scale searches, full torch.svd, re-quantisation: "
                       + ", ".join(f"{k} {v:.1f} s" for k, v in times.items()),

@@ -120,8 +120,9 @@ CASES = [
     (1152, 512, 51, True, None, [100, 300, 513]),
     (1152, 512, 128, False, 128, [129, 640]),
     # the forward microbenchmark's layer (LLaMA-3-70B up/gate projection, 10 % rank adapters), quantised and bf16 adapters
-    (28672, 8192, 1024, False, 256, [1, 16, 256, 512, 1024]),
-    (28672, 8192, 1024, False, None, [1, 16, 256, 1024]),
+    # up to the microbenchmark's largest batch (the wide tile's full-grid regime)
+    (28672, 8192, 1024, False, 256, [1, 16, 256, 512, 1024, 2048, 4096]),
+    (28672, 8192, 1024, False, None, [1, 16, 256, 1024, 4096]),
 ]
 
 
