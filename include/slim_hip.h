@@ -256,6 +256,21 @@ int slim_tridiagonalize_f32_batched(float* A, int n, int batch, float* d, float*
  * info: device status word per problem (0 = fine).  The batched form takes d / e [batch][n], Q / vecs [batch][n, n],
  * info [batch] and solves all problems in three launches. */
 int64_t slim_eigh_tail_workspace_bytes(int n, int top, int batch);
+/* The same job for the fit without an eigen-decomposition (no reference counterpart beyond the truncation of
+ * slim/lora.py:174-185): from M [batch][l, l] (symmetric positive semi-definite fp32, left intact) an orthonormal basis of
+ * the invariant subspace of the keep[b] largest eigenvalues, found as the orthogonal complement of the l - keep[b]
+ * smallest (Chebyshev-filtered subspace iteration in `n_rounds` rounds of degrees[] steps, Householder QR between; about
+ * sixty launches for three rounds).  Outputs in the layout of slim_eigh_tail_f32_batched: row l-1-j of vecs [batch][l, l]
+ * = j-th basis vector for j < keep[b], zero rows for keep[b] <= j < top; evals [batch][l]: evals[l-1-j] = its Rayleigh
+ * quotient, except evals[l-1] >= an estimate of the largest eigenvalue and evals[(l-top)/2] = mean Rayleigh quotient of
+ * the dropped block (the two values the fit's conditioning check reads).  keep / degrees: host arrays.  info [batch]:
+ * 1 = a non-finite quotient.  Limits (slim_ritz_split_supported): l <= 576, a multiple of 8; at most 80 directions
+ * dropped; 1 <= keep[b] <= top, top a multiple of 4. */
+int slim_ritz_split_supported(int l, int drop_max);
+int64_t slim_ritz_split_workspace_bytes(int l, int drop_max, int batch);
+int slim_ritz_split_f32_batched(const float* M, int l, int batch, int top, const int32_t* keep, const int32_t* degrees,
+                                int n_rounds, float* vecs, float* evals, int32_t* info, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 int slim_eigh_tail_f32(float* d, float* e, const float* Q, int n, int top, float* vecs, int32_t* info, void* workspace,
                        int64_t workspace_bytes, void* stream);
 int slim_eigh_tail_f32_batched(float* d, float* e, const float* Q, int n, int batch, int top, float* vecs, int32_t* info,

@@ -71,6 +71,13 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs g) {
         g.C += p * g.sC + w * g.sCw;
         if (g.C16) g.C16 += p * g.sC + w * g.sCw;
         if (g.poly_G) g.poly_G += p * g.sG;
+        if (g.coef) g.coef += p * g.coef_stride;
+        if (g.D1) g.D1 += p * g.sD1;
+        if (g.D2) g.D2 += p * g.sD2;
+        if (g.inv_sq_scale) {
+            const float x = g.inv_sq_scale[p * g.iss_stride];
+            g.alpha = x > 0.f ? g.alpha / (x * x) : 0.f;
+        }
     }
     f32x4 acc[2][2];
 #pragma unroll
@@ -154,15 +161,21 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs g) {
             }
         }
     }
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (g.coef) c0 = g.coef[0], c1 = g.coef[1], c2 = g.coef[2];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int r = t / 16 + 16 * it, row = row0 + r;
         if (row >= g.M) continue;
         float v[4];
+        f32x4 d1 = f32x4{0.f, 0.f, 0.f, 0.f}, d2 = d1;
+        if (g.coef && g.D1) d1 = *(const f32x4*)(g.D1 + (int64_t)row * g.ldc + col);
+        if (g.coef && g.D2) d2 = *(const f32x4*)(g.D2 + (int64_t)row * g.ldc + col);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float a = T[r * 65 + c + u];
-            v[u] = g.poly_G ? g.pb * gin[it][u] + g.pq * a + (row == col + u ? g.pa : 0.f) : g.alpha * a;
+            if (g.coef) v[u] = c0 * a + c1 * d1[u] + c2 * d2[u];
+            else v[u] = g.poly_G ? g.pb * gin[it][u] + g.pq * a + (row == col + u ? g.pa : 0.f) : g.alpha * a;
         }
         *(f32x4*)(g.C + (int64_t)row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
         if (g.C16)

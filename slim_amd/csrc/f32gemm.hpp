@@ -24,6 +24,17 @@ struct F32GemmArgs {
     const float* poly_G = nullptr;
     int64_t sG = 0;
     float pa = 0.f, pb = 0.f, pq = 0.f;
+    // optional three-term epilogue with coefficients in device memory (a recurrence whose constants a previous kernel
+    // computed): C = coef[0] * acc + coef[1] * D1 + coef[2] * D2, coef + p * coef_stride per problem p; D1 / D2 (either may
+    // be NULL, its term is then dropped) are [M, N] matrices with C's row stride, one per problem (strides sD1 / sD2)
+    const float* coef = nullptr;
+    int coef_stride = 0;
+    const float* D1 = nullptr;
+    const float* D2 = nullptr;
+    int64_t sD1 = 0, sD2 = 0;
+    // optional scale in device memory: the product is divided by x * x, x = inv_sq_scale[p * iss_stride]
+    const float* inv_sq_scale = nullptr;
+    int iss_stride = 0;
 };
 
 int slim_f32gemm_launch(const F32GemmArgs& g, void* stream);

@@ -123,6 +123,26 @@ def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, i
     return U, Ut, L, fit_info
 
 
+# The Rayleigh-Ritz step of a fit as a search for the small subspace to drop (ops.ritz_split) instead of an
+# eigen-decomposition of the l x l matrix (a chain of l dependent launches); SLIM_FIT_RITZ_SPLIT=0: the eigen-solver.
+# A fit that is being repeated (FIT_COND_FLOOR raised: its spectrum was wider than expected) takes the eigen-solver.
+FIT_RITZ_SPLIT = os.environ.get("SLIM_FIT_RITZ_SPLIT", "1") == "1"
+
+
+def rayleigh_ritz(Mg, top, keeps):
+    """The eigen-stage between the two halves of a fit for B problems: Mg [B, l, l] (destroyed by the eigen-solver) ->
+    (evals [B, l], vecs [B, l, l], info int32 [B]) as lowrank_fit_back / _group take them with e = Q = None.  keeps: per
+    problem the number of directions the caller will use (rank minus split-off columns)."""
+    B, l, _ = Mg.shape
+    keeps = [min(int(k), int(top)) for k in keeps]
+    if FIT_RITZ_SPLIT and not FIT_COND_FLOOR and ops.ritz_split_supported(l, max(l - k for k in keeps)):
+        evals, vecs, info = (lambda v, e, i: (e, v, i))(*ops.ritz_split(Mg, top, keeps))
+        return evals, vecs, info
+    d, e, Q = ops.tridiagonalize_batched(Mg)
+    info = ops.eigh_tail(d, e, Q, Mg, top)
+    return d, Mg, info
+
+
 def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
     """Rank-`rank` factors of the error matrix E [N, K] (Et its transpose): U [N, r8], Ut [r8, N], L [K, r8]
     with r8 = rank rounded up to a multiple of 8 and the columns >= rank zero (the MFMA products that consume
@@ -141,9 +161,17 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
     UO = Ct = info_o = None
     if t:
         E, UO, Ct, info_o, Et = deflate_outliers(E, Et, outliers)
-    fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
-                          ns_steps=fit_ns_steps(spread, hint), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
-                          sketch_split=FIT_SKETCH_SPLIT)
+    if (FIT_RITZ_SPLIT and not FIT_COND_FLOOR and not (FIT_CHOLESKY_QR or FIT_LIBRARY_EIGH or FIT_EXACT_FINAL)
+            and l < min(N, K) and ops.ritz_split_supported(l, l - (rank - t))):
+        # front half, the split of the Rayleigh-Ritz matrix, back half
+        M = torch.empty(1, l, l, dtype=torch.float32, device=E.device)
+        ctx = ops.lowrank_fit_front(E, Et, rf, over, fit_iters(l), M[0], **_fit_kwargs(spread, True, hint))
+        evals, vecs, info = rayleigh_ritz(M, rf, [rank - t])
+        fit = ops.lowrank_fit_back(ctx, evals, None, None, vecs, s=s, tail_info=info)
+    else:
+        fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
+                              ns_steps=fit_ns_steps(spread, hint), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
+                              sketch_split=FIT_SKETCH_SPLIT)
     return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
 
 
@@ -471,6 +499,12 @@ def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations
     shape = (N, K) if os.environ.get("SLIM_GROUP_BY_SHAPE", "0") == "1" else None
     hint = int(getattr(activations, "fit_level_hint", 0) or 0)
     return (min(N, K), rf, over, fit_ns_steps(spread, hint), shape), l
+
+
+def fit_keep(c):
+    """Directions the fit of this layer's context must deliver: the adapter rank minus the split-off outlier columns."""
+    N, K = c.E.shape
+    return c.rank - fit_plan(N, K, c.rank, c.outliers)[3]
 
 
 def add_lora_fit_front_group(ctxs, M_out, sketch_split=True):

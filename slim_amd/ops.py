@@ -488,6 +488,40 @@ def eigh_tail(d, e, Q, vecs, top):
     return info
 
 
+# rounds of the Chebyshev-filtered iteration of ritz_split (degrees of the polynomial per round)
+RITZ_SPLIT_DEGREES = (8, 12, 20)
+
+
+def ritz_split_supported(l, drop_max):
+    return bool(_lib.query("slim_ritz_split_supported", int(l), int(drop_max)))
+
+
+def ritz_split(M, top, keep, degrees=None, _workspace=False):
+    """The fit's Rayleigh-Ritz step without an eigen-decomposition: M [B, l, l] symmetric fp32 (left intact) ->
+    (vecs [B, l, l], evals [B, l], info int32 [B]) in the layout of eigh_tail: row l-1-j of vecs[b] = j-th vector of an
+    orthonormal basis of the invariant subspace of the keep[b] largest eigenvalues (zero rows for keep[b] <= j < top),
+    evals[b, l-1-j] its Rayleigh quotient.  keep: one int per problem."""
+    import ctypes
+    M = _chk(M, torch.float32, "M")
+    B, l, _ = M.shape
+    keep = [int(k) for k in keep]
+    if len(keep) != B:
+        raise ValueError("ritz_split: one `keep` per problem")
+    degrees = [int(d) for d in (degrees or RITZ_SPLIT_DEGREES)]
+    drop = max(l - k for k in keep)
+    vecs = torch.empty_like(M)
+    evals = torch.zeros(B, l, dtype=torch.float32, device=M.device)
+    info = torch.empty(B, dtype=torch.int32, device=M.device)
+    ws = _ws(_lib.query("slim_ritz_split_workspace_bytes", l, drop, B), M.device)
+    ka = (ctypes.c_int32 * B)(*keep)
+    da = (ctypes.c_int32 * len(degrees))(*degrees)
+    _lib.call("slim_ritz_split_f32_batched", _p(M), l, B, int(top), ctypes.addressof(ka), ctypes.addressof(da), len(degrees), _p(vecs),
+              _p(evals), _p(info), _p(ws), ws.numel(), _stream())
+    if _workspace:           # (tests look at the bounds the call computed)
+        return vecs, evals, info, ws
+    return vecs, evals, info
+
+
 def lowrank_fit_back(ctx, d, e, Q, vecs, s=None, tail_info=None):
     """Second half: d, e, Q of the tridiagonalised Rayleigh-Ritz matrix (one problem, or [B, ...] for a context of B fits)
     -> dict as lowrank_fit returns.  vecs: an [l, l] ([B, l, l]) fp32 scratch buffer (the Rayleigh-Ritz matrix's own
@@ -495,10 +529,16 @@ def lowrank_fit_back(ctx, d, e, Q, vecs, s=None, tail_info=None):
     results) and passes the status words."""
     import ctypes
     N, K, r, l, B = ctx["N"], ctx["K"], ctx["r"], ctx["l"], ctx.get("batch", 1)
-    dev = Q.device
-    d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
-    if Q.numel() != B * l * l or vecs.numel() != B * l * l or d.numel() != B * l or e.numel() != B * l:
-        raise ValueError("eigen-solver operands do not match the fit context")
+    dev = vecs.device
+    if tail_info is not None and e is None and Q is None:
+        # the eigen-stage has run elsewhere (eigh_tail or ritz_split): d = its eigenvalue array, vecs = its vectors
+        d, vecs = (_chk(t, torch.float32, "eig") for t in (d, vecs))
+        if vecs.numel() != B * l * l or d.numel() != B * l:
+            raise ValueError("eigen-solver operands do not match the fit context")
+    else:
+        d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
+        if Q.numel() != B * l * l or vecs.numel() != B * l * l or d.numel() != B * l or e.numel() != B * l:
+            raise ValueError("eigen-solver operands do not match the fit context")
     if tail_info is not None:
         info1 = _chk(tail_info, torch.int32, "tail_info")
         if info1.numel() != B:
@@ -560,10 +600,15 @@ def lowrank_fit_back_group(ctx, d, e, Q, vecs, ss=None, tail_info=None):
     (entries may be None).  Returns one dict(U, Ut, L, S, info) per member."""
     import ctypes
     B, r, l, shapes = ctx["batch"], ctx["r"], ctx["l"], ctx["shapes"]
-    dev = Q.device
-    d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
-    if Q.numel() != B * l * l or vecs.numel() != B * l * l or d.numel() != B * l or e.numel() != B * l:
-        raise ValueError("eigen-solver operands do not match the fit context")
+    dev = vecs.device
+    if tail_info is not None and e is None and Q is None:
+        d, vecs = (_chk(t, torch.float32, "eig") for t in (d, vecs))
+        if vecs.numel() != B * l * l or d.numel() != B * l:
+            raise ValueError("eigen-solver operands do not match the fit context")
+    else:
+        d, e, Q, vecs = (_chk(t, torch.float32, "eig") for t in (d, e, Q, vecs))
+        if Q.numel() != B * l * l or vecs.numel() != B * l * l or d.numel() != B * l or e.numel() != B * l:
+            raise ValueError("eigen-solver operands do not match the fit context")
     if tail_info is not None:
         info1 = _chk(tail_info, torch.int32, "tail_info")
         if info1.numel() != B:

@@ -533,7 +533,8 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
             def fit_back(g, d, e, Q, Mg, tail):
                 members = fit_groups[g][1]
                 if len(members) == 1:
-                    _lora.add_lora_fit_back(ctxs[members[0]], d[0], e[0], Q[0], Mg[0], tail[0:1])
+                    _lora.add_lora_fit_back(ctxs[members[0]], d[0], None if e is None else e[0], None if Q is None else Q[0], Mg[0],
+                                            tail[0:1])
                 else:
                     _lora.add_lora_fit_back_group([ctxs[i] for i in members], d, e, Q, Mg, tail)
 
@@ -575,13 +576,11 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                     fit_front(g)
                     mark("front")
                     Mg = Mb[l][b0:b0 + len(members)]
-                    d, e, Q = ops.tridiagonalize_batched(Mg)
-                    mark("tridiagonalize")
-                    tail = ops.eigh_tail(d, e, Q, Mg, fit_rank(g))
-                    mark("eigh_tail")
-                    fit_back(g, d, e, Q, Mg, tail)
+                    evals, vecs, tail = _lora.rayleigh_ritz(Mg, fit_rank(g), [_lora.fit_keep(ctxs[i]) for i in members])
+                    mark("rayleigh_ritz")
+                    fit_back(g, evals, None, None, vecs, tail)
                     mark("back")
-                    out = [d, e, Q, tail]
+                    out = [evals, vecs, tail]
                     for i in members:
                         out += finish(i)
                     mark("finish")
@@ -597,18 +596,19 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
             run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             # the eigenproblems of the block, size by size: one tridiagonalisation chain and three launches for the
             # tridiagonal stage, each carrying every problem of that size
-            tri = {l: ops.tridiagonalize_batched(Mb[l]) for l in sorted(Mb)}
-            top = {}
+            top, keeps = {}, {}
             for g in range(len(fit_groups)):
-                top[where[g][0]] = max(top.get(where[g][0], 0), fit_rank(g))
-            tails = {l: ops.eigh_tail(tri[l][0], tri[l][1], tri[l][2], Mb[l], top[l]) for l in sorted(Mb)}
+                l = where[g][0]
+                top[l] = max(top.get(l, 0), fit_rank(g))
+                keeps.setdefault(l, []).extend(_lora.fit_keep(ctxs[i]) for i in fit_groups[g][1])
+            rr = {l: _lora.rayleigh_ritz(Mb[l], top[l], keeps[l]) for l in sorted(Mb)}
 
             def back(g):
                 members = fit_groups[g][1]
                 l, b0 = where[g]
                 sl = slice(b0, b0 + len(members))
-                d, e, Q = tri[l]
-                fit_back(g, d[sl], e[sl], Q[sl], Mb[l][sl], tails[l][sl])
+                evals, vecs, tails = rr[l]
+                fit_back(g, evals[sl], None, None, vecs[sl], tails[sl])
                 return [x for i in members for x in ctxs[i].tensors()]
             run_on_streams([lambda g=g: back(g) for g in range(len(fit_groups))], dev, n_streams, ids)
             run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
