@@ -35,6 +35,10 @@ extern "C" {
  * that measured spread instead of the a-priori estimate in bits 0-7, which usually saves one or two Newton-Schulz steps
  * each; word 63 reports when the hint was too low. */
 #define SLIM_FIT_INFO_LEVEL_WORD 62
+/* Word 61 is not an error either: round(2048 * cut / mean), cut the largest eigenvalue of the fitted subspace that the fit
+ * drops, mean = trace / dimension of the Gram matrix of E: where the cut sits in the spectrum.  A caller that fits a similar
+ * matrix next may hand about 0.9 x word / 2048 to slim_lowrank_fit_set_filter. */
+#define SLIM_FIT_INFO_RATIO_WORD 61
 #define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
 #define SLIM_FIT_TWO_SIDED 2    /* alternating subspace iteration on E and E^T (two products with the N x K matrix and two
                                  * orthonormalisations per iteration) instead of the iteration on the Gram matrix of E */
@@ -262,10 +266,19 @@ int64_t slim_eigh_tail_workspace_bytes(int n, int top, int batch);
  * smallest (Chebyshev-filtered subspace iteration in `n_rounds` rounds of degrees[] steps, Householder QR between; about
  * sixty launches for three rounds).  Outputs in the layout of slim_eigh_tail_f32_batched: row l-1-j of vecs [batch][l, l]
  * = j-th basis vector for j < keep[b], zero rows for keep[b] <= j < top; evals [batch][l]: evals[l-1-j] = its Rayleigh
- * quotient, except evals[l-1] >= an estimate of the largest eigenvalue and evals[(l-top)/2] = mean Rayleigh quotient of
- * the dropped block (the two values the fit's conditioning check reads).  keep / degrees: host arrays.  info [batch]:
+ * quotient, except evals[l-1] >= an estimate of the largest eigenvalue, evals[(l-top)/2] = mean Rayleigh quotient of
+ * the dropped block and evals[l-top-1] = estimate of the largest dropped eigenvalue (the values the fit's conditioning
+ * check reads).  keep / degrees: host arrays.  info [batch]:
  * 1 = a non-finite quotient.  Limits (slim_ritz_split_supported): l <= 576, a multiple of 8; at most 80 directions
  * dropped; 1 <= keep[b] <= top, top a multiple of 4. */
+/* Chebyshev-filtered subspace iteration for the NEXT slim_lowrank_fit_front / _front_batched / _front_group call on the
+ * calling thread (the request is consumed by it; other threads are not affected): ratios[b] > 0 per problem of that call,
+ * beta_b = ratios[b] * trace(C_b) / Dm the upper end of the interval [0, beta_b] of eigenvalues of C_b = E^T E (or E E^T)
+ * that the filter damps -- it must lie below the eigenvalues the fit is to keep (status word SLIM_FIT_INFO_RATIO_WORD of a
+ * similar fit says where they end; word SLIM_FIT_INFO_COND_WORD asks for a repeat when beta turned out too high).  The
+ * call then runs (n_iter + 1) / 2 rounds of [degree-2 Chebyshev polynomial of C, orthonormalisation sized for 2^ns_bits]
+ * instead of n_iter + 1 rounds of [C, orthonormalisation].  count = 0 withdraws a request. */
+int slim_lowrank_fit_set_filter(const float* ratios, int count, int ns_bits);
 int slim_ritz_split_supported(int l, int drop_max);
 int64_t slim_ritz_split_workspace_bytes(int l, int drop_max, int batch);
 int slim_ritz_split_f32_batched(const float* M, int l, int batch, int top, const int32_t* keep, const int32_t* degrees,

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "slim_eigh_tail_f32": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, i64, vp]),
     "slim_eigh_tail_workspace_bytes": (i64, [i32, i32, i32]),
     "slim_eigh_tail_f32_batched": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, i64, vp]),
+    "slim_lowrank_fit_set_filter": (i32, [vp, i32, i32]),
     "slim_ritz_split_supported": (i32, [i32, i32]),
     "slim_ritz_split_workspace_bytes": (i64, [i32, i32, i32]),
     "slim_ritz_split_f32_batched": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, i64, vp]),

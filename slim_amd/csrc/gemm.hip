@@ -128,6 +128,8 @@ __device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, const GemmArgs& gi
         if (g.slab) g.slab += bz * g.sSlab;
         if (g.poly_G) g.poly_G += bz * g.poly_sG;
         if (g.poly_scal) g.poly_scal += bz * g.poly_sScal;
+        if (g.add16) g.add16 += bz * g.sAdd;
+        if (g.add_coef) g.add_coef += bz * g.sAddCoef;
     }
 
 }
@@ -160,6 +162,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
     __syncthreads();
     gemm_stamp(g, 4);
     const int t = threadIdx.x;
+    if (g.add16) {
+        // the addend joins the tile in LDS, so that every output form (and the transposed copy) carries it
+        const float cf = g.add_coef ? *g.add_coef : 1.f;
+        constexpr int TPRA = BN / 8;
+        const int c = (t % TPRA) * 8, col = col0 + c;
+        if (col < g.N) {
+            const bool v8 = g.N - col >= 8 && (g.ldadd & 7) == 0 && ((uintptr_t)g.add16 & 15) == 0;
+            for (int r = t / TPRA; r < BM && row0 + r < g.M; r += NT / TPRA) {
+                const bf16_t* p = g.add16 + (int64_t)(row0 + r) * g.ldadd + col;
+                if (v8) {
+                    const u16x8 d = *(const u16x8*)p;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) T[r * TS + c + u] += cf * bf16_to_f32(d[u]);
+                } else {
+                    for (int u = 0; u < 8 && col + u < g.N; ++u) T[r * TS + c + u] += cf * bf16_to_f32(p[u]);
+                }
+            }
+        }
+        __syncthreads();
+    }
     const bool split = ALL_FORMS && g.splits > 1;
     // Row-wise outputs.  On this ISA loads and stores retire through one in-order counter, so a loop that waits for a
     // load also waits for every earlier store's acknowledgement (a round trip to L2 per iteration): the common case
@@ -666,6 +688,8 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     SLIM_REQUIRE(g.C32 || g.C16 || g.Ct16 || g.Wn, "slim_gemm_nt_bf16: no output requested");
     SLIM_REQUIRE(!g.Ct16 || (((uintptr_t)g.Ct16 % 8) == 0 && g.beta == 0.f),
                  "slim_gemm_nt_bf16: Ct must be 8-byte aligned and cannot be combined with beta");
+    SLIM_REQUIRE(!g.add16 || (g.splits <= 1 && g.alpha == 1.f && g.beta == 0.f && !g.poly_G && !g.Wn && !g.sym),
+                 "slim_gemm_nt_bf16: the addend needs an unsplit plain product");
     SLIM_REQUIRE(!g.poly_G || (g.C16 && !g.C32 && !g.Ct16 && !g.Wn && g.splits <= 1 && g.beta == 0.f && g.M == g.N),
                  "slim_gemm_nt_bf16: the polynomial epilogue writes C_bf16 only, of a square product");
     SLIM_REQUIRE(g.nptr == 0 || (g.nptr == g.batch && g.nptr <= GEMM_MAX_PTRS && g.splits <= 1), "slim_gemm_nt_bf16: bad pointer batch");

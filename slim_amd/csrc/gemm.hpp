@@ -63,6 +63,13 @@ struct GemmArgs {
     // split-K only: the bf16 output is C - c16_diag I (the shifted Gram matrix of a Newton-Schulz step); C32 is unshifted
     float c16_diag = 0.f;
     int64_t poly_sG = 0, poly_sScal = 0;      // batch strides of poly_G / poly_scal
+    // optional addend (no split-K, alpha == 1, beta == 0): every output form receives acc + (*add_coef) * add16, add16 a
+    // bf16 [M, N] matrix (row stride ldadd), add_coef a float in device memory (a recurrence whose constant an earlier
+    // kernel computed); batch strides sAdd / sAddCoef
+    const bf16_t* add16 = nullptr;
+    int64_t ldadd = 0, sAdd = 0;
+    const float* add_coef = nullptr;
+    int64_t sAddCoef = 0;
     // tuning aid (slim_gemm_set_trace): when set, workgroup w < trace_cap stores 100 MHz timestamps at
     // trace[8 w ..]: kernel entry, first tile staged, K-loop done, epilogue done
     int64_t* trace = nullptr;

@@ -73,6 +73,7 @@ int solver_handle(hipStream_t st, rb_handle* out) {
     return SLIM_OK;
 }
 
+#define SCAL_STRIDE 4        // floats of per-problem scalars (FitWs::scal): 0 Newton-Schulz scale, 1-3 see cheb_prepare_kernel
 // ---- small kernels -----------------------------------------------------------------------------
 // Every kernel below works on a strided batch of identical problems: the last grid dimension in use selects
 // the problem, `stride` arguments are in elements.
@@ -152,7 +153,13 @@ __global__ void top_eigvecs_kernel(const float* __restrict__ vecs, const float* 
 // later > 0 (half a level of slack), else for singular value ratios up to 2^cond_e (an application of the Gram matrix
 // squares the conditioning, which the fit allows for by itself).  Word SLIM_FIT_INFO_LEVEL_WORD receives the ratio found,
 // ceil(4 log2(largest / weakest eigenvalue that matters)): what a caller needs to size the next, similar fit.
-__global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r, int batch, int levels, int* __restrict__ info) {
+// scal (cheb_prepare_kernel's, optional): word SLIM_FIT_INFO_RATIO_WORD receives round(2048 * cut / mean), cut =
+// evals[l - r - 1] the largest eigenvalue the fit drops (the eigen-solver's value, or the split's estimate of it), mean the
+// mean eigenvalue of the Gram matrix: where the cut sits in the spectrum -- the ratio a Chebyshev-filtered fit of a similar
+// matrix is given; and a fit that was filtered with an interval reaching to within 3 % of its cut or above it (wanted
+// directions were not amplified) asks to be repeated.
+__global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r, int batch, int levels, int* __restrict__ info,
+                                  const float* __restrict__ scal = nullptr) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const int cond_e = levels & 0xff, later = (levels >> 8) & 0xff;
@@ -170,8 +177,46 @@ __global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r,
             else if (need <= cond_e) need = 0;              // already at the widest schedule
         }
     }
+    int ratio_q = 0;
+    if (scal) {
+        const float mean = scal[b * SCAL_STRIDE + 1], beta = scal[b * SCAL_STRIDE + 2];
+        const float cut = l - r - 1 >= 0 ? evals[(int64_t)b * l + l - r - 1] : 0.f;
+        if (mean > 0.f && cut > 0.f) {
+            const float q = 2048.f * cut / mean;
+            ratio_q = q > 65535.f ? 65535 : (int)(q + 0.5f);
+        }
+        if (beta > 0.f && !(beta <= 0.97f * cut) && need < 1) need = 1;
+    }
     info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_COND_WORD] = need;
     info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_LEVEL_WORD] = found;
+    info[(int64_t)b * SLIM_FIT_INFO_WORDS + SLIM_FIT_INFO_RATIO_WORD] = ratio_q;
+}
+
+// Chebyshev-filtered subspace iteration: set-up per problem (one workgroup each).  mean = trace(C) / Dm (the mean eigenvalue
+// of the Gram matrix C: the scale a caller's `ratio` refers to) -> scal[1]; ratio > 0: beta = ratio * mean -> scal[2], the
+// upper end of the interval [0, beta] the filter damps; C <- C - (beta / 2) I in place (bf16); scal[3] = -beta^2 / 8.
+// With C' = C - (beta / 2) I the degree-2 Chebyshev polynomial of the first kind on [0, beta] applied to a block Y is,
+// up to a constant factor, C' (C' Y) - (beta^2 / 8) Y: two products with C' and one addend.
+__global__ __launch_bounds__(256) void cheb_prepare_kernel(bf16_t* __restrict__ C16, int64_t sC, int Dm, const float* __restrict__ ratios,
+                                                           float* __restrict__ scal) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    bf16_t* C = C16 + (int64_t)b * sC;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < Dm; i += 256) s += (double)bf16_to_f32(C[(int64_t)i * Dm + i]);
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)Dm);
+    const float ratio = ratios ? ratios[b] : 0.f;
+    const float beta = ratio > 0.f ? ratio * mean : 0.f;
+    if (threadIdx.x == 0) {
+        scal[b * SCAL_STRIDE + 1] = mean;
+        scal[b * SCAL_STRIDE + 2] = beta;
+        scal[b * SCAL_STRIDE + 3] = -0.125f * beta * beta;
+    }
+    if (beta > 0.f)
+        for (int i = threadIdx.x; i < Dm; i += 256) C[(int64_t)i * Dm + i] = f32_to_bf16(bf16_to_f32(C[(int64_t)i * Dm + i]) - 0.5f * beta);
 }
 
 // bf16 identity [batch][rows, l] and its transpose [batch][l, rows] (rows == l)
@@ -222,7 +267,6 @@ extern "C" int slim_scale_rows_bf16(void* L, const float* s, int64_t K, int64_t 
 // scal[0] = 1 / sqrt(||G||_F): after X <- scal * X every singular value of X is <= 1 (and >= l^(-1/4)
 // of the largest), the range in which the polynomial iteration below is stable.
 #define FRO_BLOCKS 64
-#define SCAL_STRIDE 4
 __global__ __launch_bounds__(256) void fro_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
     __shared__ double red[4];
     g += (int64_t)blockIdx.y * n;
@@ -833,14 +877,98 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
 }
 
 
+// ---- Chebyshev filter request ---------------------------------------------------------------------------------------------
+// slim_lowrank_fit_set_filter leaves, for the NEXT front-half call on the calling thread (it is consumed there), one ratio
+// per problem and the conditioning (log2) the orthonormalisations of the filtered rounds are sized for.
+#define FILTER_MAX 1024
+static thread_local float tl_filter_ratio[FILTER_MAX];
+static thread_local int tl_filter_count = 0, tl_filter_bits = 0;
+extern "C" int slim_lowrank_fit_set_filter(const float* ratios, int count, int ns_bits) {
+    SLIM_REQUIRE(count >= 0 && count <= FILTER_MAX && (count == 0 || ratios) && ns_bits >= 0 && ns_bits <= NS_SCHED_MAX_E,
+                 "slim_lowrank_fit_set_filter: bad arguments");
+    for (int i = 0; i < count; ++i) {
+        SLIM_REQUIRE(ratios[i] >= 0.f && ratios[i] < 64.f, "slim_lowrank_fit_set_filter: ratios must lie in [0, 64)");
+        tl_filter_ratio[i] = ratios[i];
+    }
+    tl_filter_count = count;
+    tl_filter_bits = ns_bits;
+    return SLIM_OK;
+}
+struct FilterReq {
+    int count = 0, bits = 0;
+    float ratio[FILTER_MAX];
+};
+// (takes the request of this thread and clears it; `on` only when every one of `batch` problems has a positive ratio)
+static bool take_filter(int batch, float* ratios_out, int* bits_out) {
+    const int count = tl_filter_count;
+    tl_filter_count = 0;
+    if (count != batch) return false;
+    for (int i = 0; i < batch; ++i) {
+        if (!(tl_filter_ratio[i] > 0.f)) return false;
+        ratios_out[i] = tl_filter_ratio[i];
+    }
+    *bits_out = tl_filter_bits;
+    return true;
+}
+
 // ---- the fit by subspace iteration on the Gram matrix ------------------------------------------------------------------
 // Subspace iteration on the symmetric matrix C [batch][Dm, Dm] (bf16): n_iter + 1 applications of C to an l-column
 // iterate that starts as a Gaussian matrix, each followed by an orthonormalisation (the last one to the accuracy of a
 // final basis).  Pb: three rotating buffer pairs of Dm rows; *a_out = index of the pair that holds the basis P.
-static int gram_iterate(Pair* Pb, const bf16_t* C16, int64_t sC, int batch, int64_t Dm, int l, int n_iter, uint32_t seed,
-                        int flags, int cond_e, FitWs& w, float* sk_slab, int64_t sSk, void* stream, int* a_out, int* ninfo) {
+//
+// filter_ratios (host array of `batch` positive ratios, or NULL): the Chebyshev-filtered iteration instead.  With beta =
+// ratio * trace(C) / Dm per problem (cheb_prepare_kernel), every round applies the degree-2 Chebyshev polynomial on
+// [0, beta] -- eigenvalues below beta, the unwanted end of the spectrum, stay bounded while the wanted ones grow like
+// cosh(2 acosh(2 lambda / beta - 1)) -- as two products with C - (beta / 2) I and one addend, then orthonormalises:
+// (n_iter + 1) / 2 rounds, orthonormalisations sized for 2^filter_bits (two levels more for the first, whose start is random).
+// Per application of C the gap between a wanted eigenvalue and beta closes several times faster than under the plain
+// iteration (flat spectra: lambda_r / lambda_(l+1) = 1.07 per application against 1.6 per degree), and a round has ONE
+// orthonormalisation for two applications.  C is modified in place (its diagonal is shifted).
+static int gram_iterate(Pair* Pb, bf16_t* C16, int64_t sC, int batch, int64_t Dm, int l, int n_iter, uint32_t seed,
+                        int flags, int cond_e, FitWs& w, float* sk_slab, int64_t sSk, void* stream, int* a_out, int* ninfo,
+                        const float* filter_ratios = nullptr, int filter_bits = 0) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t sP = Dm * l;
+    {
+        // the mean eigenvalue of C (reported with the fit's status words), and the filter's set-up
+        float* dev_ratios = nullptr;
+        if (filter_ratios) {
+            dev_ratios = w.evals;                                  // [batch][l] floats, free until the eigen-stage
+            SLIM_HIP(hipMemcpyAsync(dev_ratios, filter_ratios, (size_t)batch * sizeof(float), hipMemcpyHostToDevice, st));
+        }
+        cheb_prepare_kernel<<<batch, 256, 0, st>>>(C16, sC, (int)Dm, dev_ratios, w.scal);
+        SLIM_LAUNCH_CHECK();
+    }
+    if (filter_ratios) {
+        const int64_t n = (int64_t)l * Dm;
+        randn_bf16_kernel<<<dim3((unsigned)ceil_div64(n, 256), (unsigned)batch), 256, 0, st>>>(Pb[1].Xt, n, seed, sP);
+        SLIM_LAUNCH_CHECK();
+        const int rounds = (n_iter + 1) / 2 > 0 ? (n_iter + 1) / 2 : 1;
+        int src = 1, a = 1;
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int d1 = (src + 1) % 3, d2 = (src + 2) % 3;
+            // W1^T = P^T C' ;  Y^T = W1^T C' - (beta^2 / 8) P^T  (both orientations of Y for the orthonormalisation)
+            CHK(nt(batch, Pb[src].Xt, Dm, sP, C16, Dm, sC, l, (int)Dm, (int)Dm, nullptr, Pb[d1].Xt, Dm, nullptr, 0, stream));
+            {
+                GemmArgs g;
+                g.A = Pb[d1].Xt, g.lda = Dm, g.B = C16, g.ldb = Dm;
+                g.M = l, g.N = (int)Dm, g.Kd = (int)Dm;
+                g.C16 = Pb[d2].Xt, g.ldc16 = Dm, g.Ct16 = Pb[d2].X, g.ldct = l;
+                g.batch = batch;
+                g.sA = sP, g.sB = sC, g.sC16 = g.sCt = sP;
+                g.add16 = Pb[src].Xt, g.ldadd = Dm, g.sAdd = sP;
+                g.add_coef = w.scal + 3, g.sAddCoef = SCAL_STRIDE;
+                CHK(slim_gemm_launch(g, stream));
+            }
+            int bits = filter_bits + (rd == 0 ? 2 : 0);
+            bits = bits > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : bits;
+            CHK(orth(Pb, d2, Dm, l, rd + 1 == rounds, flags, bits, w, *ninfo, stream, &a));
+            *ninfo += 2;
+            src = a;
+        }
+        *a_out = a;
+        return SLIM_OK;
+    }
     // cond_e: encoded levels (ns_levels_clamped).  An application of C squares the conditioning inside the subspace
     const int est = 2 * (cond_e & 0xff) > NS_SCHED_MAX_E ? NS_SCHED_MAX_E : 2 * (cond_e & 0xff);
     const int later = (cond_e >> 8) & 0xff ? (cond_e >> 8) & 0xff : est;
@@ -909,7 +1037,11 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
                 g.sym = 1;
                 CHK(slim_gemm_launch(g, stream));
             }
-            CHK(gram_iterate(Pb, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond_e, w, sk_slab, sSk, stream, &a, &ninfo));
+            float fr[FILTER_MAX];
+            int fbits = 0;
+            const bool filt = phase == FIT_FRONT && take_filter(batch, fr, &fbits);
+            CHK(gram_iterate(Pb, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond_e, w, sk_slab, sSk, stream, &a, &ninfo,
+                             filt ? fr : nullptr, fbits));
         }
         // Z^T = P^T E^T (operand E [N, K]: Z = E P) or P^T E (operand E^T: Z = E^T P) -> Z^T [l, Dx] and Z [Dx, l]
         CHK(nt(batch, Pb[a].Xt, Dm, sP, right ? Eb : Etb, Dm, sE, l, (int)Dx, (int)Dm, nullptr, Zb.Xt, Dx, Zb.X, l, stream, sk_slab, sSk));
@@ -951,7 +1083,7 @@ static int gram_fit_impl(int phase, const void* E, const void* Et, int batch, in
     const float* vecs = phase == FIT_BACK ? ext_vecs : w.G;
     const float* evals = phase == FIT_BACK ? ext_evals : w.evals;
     if (l < Dm) {
-        cond_check_kernel<<<(batch + 63) / 64, 64, 0, st>>>(evals, l, r, batch, cond_e, w.info);
+        cond_check_kernel<<<(batch + 63) / 64, 64, 0, st>>>(evals, l, r, batch, cond_e, w.info, w.scal);
         SLIM_LAUNCH_CHECK();
     }
     const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, (unsigned)batch);
@@ -1401,7 +1533,8 @@ extern "C" int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_it
     SLIM_HIP(hipMemsetAsync(w.info, 0, SLIM_FIT_INFO_WORDS * sizeof(int), st));
     const int cond = ns_levels_clamped(cond_e);
     int a = 0, ninfo = 0;
-    CHK(gram_iterate(w.A, (const bf16_t*)C16, Dm * Dm, 1, Dm, l, n_iter, seed, flags & ~(SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL),
+    // (no filter on this path: the caller's matrix is only read)
+    CHK(gram_iterate(w.A, (bf16_t*)C16, Dm * Dm, 1, Dm, l, n_iter, seed, flags & ~(SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL),
                      cond, w, w.sketch_slab, (int64_t)SKETCH_MAX_SPLITS * l * Dm, stream, &a, &ninfo));
     const size_t bytes = (size_t)Dm * l * sizeof(bf16_t);
     SLIM_HIP(hipMemcpyAsync(P, w.A[a].X, bytes, hipMemcpyDeviceToDevice, st));
@@ -1588,7 +1721,11 @@ extern "C" int slim_lowrank_fit_front_group(const void* const* E, const void* co
         CHK(slim_gemm_launch(g, stream));
     }
     int a = 0, ninfo = 0;
-    CHK(gram_iterate(w.B, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond, w, sk_slab, sSk, stream, &a, &ninfo));
+    float fr[FILTER_MAX];
+    int fbits = 0;
+    const bool filt = take_filter(batch, fr, &fbits);
+    CHK(gram_iterate(w.B, w.C16, sC, batch, Dm, l, n_iter, seed, flags, cond, w, sk_slab, sSk, stream, &a, &ninfo, filt ? fr : nullptr,
+                     fbits));
     // the projections Z^T = P^T E^T (or P^T E): members with one long dimension, un-split, as one launch (operands of the
     // members in separate allocations, outputs strided in the workspace); otherwise member by member
     const bool proj_batched = same_dx && !sk_slab && batch > 1 && batch <= GEMM_MAX_PTRS;
@@ -1648,7 +1785,7 @@ extern "C" int slim_lowrank_fit_back_group(const int64_t* Ns, const int64_t* Ks,
         SLIM_LAUNCH_CHECK();
     }
     ninfo += 1;
-    cond_check_kernel<<<(batch + 63) / 64, 64, 0, st>>>(evals, l, r, batch, cond_e, w.info);
+    cond_check_kernel<<<(batch + 63) / 64, 64, 0, st>>>(evals, l, r, batch, cond_e, w.info, w.scal);
     SLIM_LAUNCH_CHECK();
     const int64_t sP = Dm * l, sZ = Dxm * l, sG = (int64_t)l * l;
     const dim3 grid((unsigned)((l + 255) / 256), (unsigned)r, 1);

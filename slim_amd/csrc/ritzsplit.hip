@@ -434,7 +434,7 @@ __global__ __launch_bounds__(1024) void rs_apply_kernel(const float* __restrict_
 
 // evals[b][l - 1 - j] = <row l-1-j of W M, row l-1-j of W> for j < top (0 beyond keep), one wave per row; then the two
 // slots the fit's conditioning check reads: evals[l - 1] = estimate of the largest eigenvalue of M, evals[(l - top) / 2] =
-// mean Rayleigh quotient of the dropped block.  info[b] = 1 when a quotient is not finite.
+// mean Rayleigh quotient of the dropped block, evals[l - top - 1] = estimate of the largest dropped eigenvalue.  info[b] = 1 when a quotient is not finite.
 __global__ __launch_bounds__(256) void rs_evals_kernel(const float* __restrict__ WM, const float* __restrict__ vecs, int l, int top,
                                                        RsKeep keep, const float* __restrict__ scal, float* __restrict__ evals,
                                                        int32_t* __restrict__ info) {
@@ -455,6 +455,9 @@ __global__ __launch_bounds__(256) void rs_evals_kernel(const float* __restrict__
         if (j == 0) out = fmaxf(sc[SC_HI], out);
         evals[(int64_t)b * l + row] = out;
         if (j == 0 && (l - top) / 2 < keep.c[b]) evals[(int64_t)b * l + (l - top) / 2] = sc[SC_LO];
+        // the largest eigenvalue that is dropped: the last bound of the iteration lies 3-8 % above it
+        if (j == 0 && l - top - 1 >= 0 && l - top - 1 < keep.c[b] && l - top - 1 != (l - top) / 2)
+            evals[(int64_t)b * l + l - top - 1] = sc[SC_A] / 1.05f;
     }
 }
 

@@ -55,6 +55,7 @@ def fit_ns_steps(spread, hint=0):
     if os.environ.get("SLIM_FIT_COND_E"):          # tuning aid: fixed value
         return int(os.environ["SLIM_FIT_COND_E"])
     level = int(min(6, max(1, FIT_COND_FLOOR, math.ceil(math.log2(max(float(spread) / 2.0, 1.0))))))
+    hint = hint_level(hint)
     if hint and not FIT_COND_FLOOR and FIT_LEVEL_HINTS:
         level |= int(min(12, max(2, hint))) << 8
     return level
@@ -64,12 +65,47 @@ def fit_ns_steps(spread, hint=0):
 FIT_LEVEL_HINTS = os.environ.get("SLIM_FIT_LEVEL_HINTS", "1") == "1"
 
 
-def level_hint_from_status(word):
-    """The hint for the next similar fit from status word SLIM_FIT_INFO_LEVEL_WORD of a finished one (0: none): the
-    measured log2 spread of the Gram matrix's eigenvalues inside the subspace plus one level, because the subspaces of the
-    iterations before the last are not converged and a little worse conditioned."""
+def level_hint_from_status(word, ratio_word=0):
+    """The hint for the next similar fit from the status words SLIM_FIT_INFO_LEVEL_WORD (and SLIM_FIT_INFO_RATIO_WORD) of a
+    finished one (0: none), packed into one int: bits 0-7 the measured log2 spread of the Gram matrix's eigenvalues inside
+    the subspace plus one level (the subspaces of the iterations before the last are not converged and a little worse
+    conditioned), bits 8-15 the level word itself (4 log2 of that spread), bits 16-31 the ratio word (2048 x where the
+    dropped part of the spectrum sits relative to the mean eigenvalue of the Gram matrix: what the Chebyshev-filtered
+    iteration of the next similar fit is given, see filter_plan)."""
     import math
-    return int(math.ceil(word / 4.0 + 1.0)) if word > 0 else 0
+    if word <= 0:
+        return 0
+    return int(math.ceil(word / 4.0 + 1.0)) | (min(int(word), 255) << 8) | (min(max(int(ratio_word), 0), 65535) << 16)
+
+
+def hint_level(hint):
+    return int(hint) & 0xff
+
+
+# Chebyshev-filtered subspace iteration (ops.set_fit_filter) for fits that carry the ratio of a similar finished fit:
+# FIT_FILTER_ROUNDS rounds of [degree-2 polynomial of the Gram matrix, one orthonormalisation] instead of FIT_ITERS + 1
+# rounds of [Gram matrix, orthonormalisation].  The damped interval ends at FIT_FILTER_MARGIN x the largest eigenvalue the
+# previous fit dropped (relative to the mean eigenvalue of the Gram matrix); a fit whose own cut lies lower asks to be
+# repeated (status word 63) and is then run without the filter.  SLIM_FIT_FILTER=0: never.
+FIT_FILTER = os.environ.get("SLIM_FIT_FILTER", "1") == "1"
+FIT_FILTER_ROUNDS = int(os.environ.get("SLIM_FIT_FILTER_ROUNDS", "3"))
+FIT_FILTER_MARGIN = float(os.environ.get("SLIM_FIT_FILTER_MARGIN", "0.8"))
+
+
+def filter_plan(hints):
+    """(ratios per member, bits, n_iter) of the filtered iteration for fits with these packed hints, or None when any of
+    them carries no ratio (or the filter is off, or the fits are being repeated)."""
+    import math
+    if not FIT_FILTER or FIT_COND_FLOOR or FIT_CHOLESKY_QR or FIT_EXACT_FINAL or not FIT_LEVEL_HINTS:
+        return None
+    hints = [int(h) for h in hints]
+    if not hints or any((h >> 16) <= 0 for h in hints):
+        return None
+    ratios = [(h >> 16) / 2048.0 * FIT_FILTER_MARGIN for h in hints]
+    # largest eigenvalue over the interval's end: the measured spread (word / 4 = log2), 5 % slack, the margin
+    kappa = max(2.0 ** (((h >> 8) & 0xff) / 4.0) for h in hints) * 1.05 / FIT_FILTER_MARGIN      # (the cut lies above `lo`)
+    bits = int(math.ceil(math.log2(2.0 * (2.0 * kappa - 1.0) ** 2 - 1.0) + 0.5))
+    return ratios, max(2, min(bits, 12)), 2 * FIT_FILTER_ROUNDS - 1
 
 
 # lower bound of fit_ns_steps; raised by the driver while it repeats fits whose conditioning was underestimated
@@ -165,7 +201,9 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
             and l < min(N, K) and ops.ritz_split_supported(l, l - (rank - t))):
         # front half, the split of the Rayleigh-Ritz matrix, back half
         M = torch.empty(1, l, l, dtype=torch.float32, device=E.device)
-        ctx = ops.lowrank_fit_front(E, Et, rf, over, fit_iters(l), M[0], **_fit_kwargs(spread, True, hint))
+        plan = filter_plan([hint])
+        ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
+        ctx = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M[0], **_fit_kwargs(spread, True, hint))
         evals, vecs, info = rayleigh_ritz(M, rf, [rank - t])
         fit = ops.lowrank_fit_back(ctx, evals, None, None, vecs, s=s, tail_info=info)
     else:
@@ -205,7 +243,9 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
     p = dict(N=N, K=K, rank=rank, t=t, UO=None, Ct=None, info_o=None)
     if t:
         E, Et, p["UO"], p["Ct"], p["info_o"] = deflated if deflated is not None else deflated_pair(E, Et, outliers)
-    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split, hint))
+    plan = filter_plan([hint]) if l < min(N, K) else None
+    ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
+    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split, hint))
     return p
 
 
@@ -215,7 +255,7 @@ def deflated_pair(E, Et, outliers):
     return E2, E2t, UO, Ct, info_o
 
 
-def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None):
+def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None, hints=None):
     """fit_error_matrix_front for B layers in lockstep.  Their shapes, ranks and deflation sets may differ as long as the
     short dimension min(N, K) and the fit's plan (rank asked of the randomized fit, oversampling, subspace dimension, see
     fit_plan) agree: the subspace iteration then runs as one batched chain.  M_out [B, l, l].  Every member's result
@@ -241,7 +281,10 @@ def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch
         Eds.append(E)
         Etds.append(Et)
         p["members"].append(m)
-    p["ctx"] = ops.lowrank_fit_front_group(Eds, Etds, rf, over, fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split, hint))
+    plan = filter_plan(hints if hints is not None else [hint] * B)
+    ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
+    p["ctx"] = ops.lowrank_fit_front_group(Eds, Etds, rf, over, plan[2] if plan else fit_iters(l), M_out,
+                                           **_fit_kwargs(spread, sketch_split, hint))
     return p
 
 
@@ -498,7 +541,7 @@ def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations
         return ("alone", id(module)), l            # modes and ranks that do not run as a mixed-shape group
     shape = (N, K) if os.environ.get("SLIM_GROUP_BY_SHAPE", "0") == "1" else None
     hint = int(getattr(activations, "fit_level_hint", 0) or 0)
-    return (min(N, K), rf, over, fit_ns_steps(spread, hint), shape), l
+    return (min(N, K), rf, over, fit_ns_steps(spread, hint), filter_plan([hint]) is not None, shape), l
 
 
 def fit_keep(c):
@@ -516,7 +559,7 @@ def add_lora_fit_front_group(ctxs, M_out, sketch_split=True):
         raise ValueError("the layers of a group must share their Newton-Schulz depth")
     ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], [c.rank for c in ctxs],
                                                    [c.outliers for c in ctxs], ctxs[0].spread, M_out, sketch_split,
-                                                   ctxs[0].level_hint, [c.deflated for c in ctxs])
+                                                   ctxs[0].level_hint, [c.deflated for c in ctxs], [c.level_hint for c in ctxs])
 
 
 def add_lora_fit_back_group(ctxs, d, e, Q, vecs, tail_info=None):

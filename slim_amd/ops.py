@@ -437,6 +437,15 @@ def fit_subspace(N, K, r, oversample):
     return l - l % 8
 
 
+def set_fit_filter(ratios, bits):
+    """Request (ratios non-empty) or withdraw the Chebyshev-filtered iteration for the next lowrank_fit_front* call on this
+    thread (slim_lowrank_fit_set_filter): one ratio per problem of that call."""
+    import ctypes
+    n = len(ratios)
+    arr = (ctypes.c_float * max(n, 1))(*[float(x) for x in ratios])
+    _lib.call("slim_lowrank_fit_set_filter", ctypes.addressof(arr), n, int(bits))
+
+
 def lowrank_fit_front(E, Et, r, oversample, n_iter, M_out, seed=0, flags=0, ns_steps=0):
     """First half of lowrank_fit: everything up to the l x l Rayleigh-Ritz matrix, which is written to M_out (fp32 [l, l]).
     E [B, N, K] (Et [B, K, N], M_out [B, l, l]) runs B same-shape fits in lockstep.

@@ -335,7 +335,8 @@ def check_fit_status(items, levels=None):
     orthonormalisation is non-zero): such a fit leaves arbitrary adapters and a residual weight quantised against them.
     Returns {index in items: level} for the fits that ask to be repeated with orthonormalisations sized for a wider
     spread of singular values (their last status word).  levels (a dict, optional) receives {index in items: the spread
-    the fit measured} (status word SLIM_FIT_INFO_LEVEL_WORD; fits that report none are left out).  One host
+    the fit measured, where its cut sits} (status words SLIM_FIT_INFO_LEVEL_WORD and SLIM_FIT_INFO_RATIO_WORD; fits that
+    report none are left out).  One host
     synchronisation for the whole block."""
     named = [(i, name, lin.lora_fit_info) for i, (name, lin, _) in enumerate(items)
              if getattr(lin, "lora_fit_info", None) is not None]
@@ -344,17 +345,18 @@ def check_fit_status(items, levels=None):
     # one stacked tensor and a handful of launches for the whole block (per-linear reductions cost the host more than the GPU)
     words = torch.stack([info.reshape(-1)[-64:].to(torch.int32) for _, _, info in named])
     extra = [info.reshape(-1)[:-64].ne(0).any() for _, _, info in named if info.numel() > 64]
-    flags = torch.cat([words[:, :-2].ne(0).any(1, keepdim=True).to(torch.int32), words[:, -1:], words[:, -2:-1]], 1)
+    # (the last three words are reports, not errors: conditioning request, measured spread, where the cut sits)
+    flags = torch.cat([words[:, :-3].ne(0).any(1, keepdim=True).to(torch.int32), words[:, -1:], words[:, -2:-1], words[:, -3:-2]], 1)
     if extra:
         flags[[i for i, (_, _, info) in enumerate(named) if info.numel() > 64], 0] |= torch.stack(extra).to(torch.int32)
     flags = flags.cpu().tolist()
-    failed = [(name, info[:-2].cpu().tolist()) for (_, name, info), f in zip(named, flags) if f[0]]
+    failed = [(name, info[:-3].cpu().tolist()) for (_, name, info), f in zip(named, flags) if f[0]]
     if failed:
         from ._lib import SlimHipError, ERR_SOLVER
         raise SlimHipError("low-rank fit", ERR_SOLVER, "; ".join(
             f"{name}: status words {[w for w in words if w][:8]}" for name, words in failed))
     if levels is not None:
-        levels.update({i: int(f[2]) for (i, _, _), f in zip(named, flags) if f[2] > 0})
+        levels.update({i: (int(f[2]), int(f[3])) for (i, _, _), f in zip(named, flags) if f[2] > 0})
     return {i: int(f[1]) for (i, _, _), f in zip(named, flags) if f[1] > 0}
 
 
@@ -402,7 +404,7 @@ def compress_linears(items, dev, *args, level_hints=None, **kwargs):
         found.update({order[j]: w for j, w in refound.items()})
     if level_hints is not None:
         for i, word in found.items():
-            level_hints[keys[i]] = _lora.level_hint_from_status(word)
+            level_hints[keys[i]] = _lora.level_hint_from_status(*word)
 
 
 def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,

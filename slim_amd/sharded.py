@@ -253,7 +253,7 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         lin.lora_left = torch.nn.Parameter(L[:, :j.rank_].contiguous() * sq)
         lin.lora_right = torch.nn.Parameter(ops.transpose(U)[:j.rank_].contiguous() * sq)
         lin.register_forward_hook(add_lora_hook)
-        bad = j.info[:-2].ne(0).any()
+        bad = j.info[:-3].ne(0).any()
         if j.info_o is not None:
             bad = bad | j.info_o.ne(0).any()
         status[idx, 0] = bad.to(torch.int32)

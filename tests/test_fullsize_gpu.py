@@ -58,11 +58,12 @@ def _excess(E, U, L, rank, sv=None):
 def _hinted_refit(ops, E, rank, outl, spread, info):
     """The fit again, sized as the driver sizes the same linear of the next block: from the spread this fit measured
     (status word 62).  Returns (U, L, hint) -- the second fit must not ask to be repeated."""
-    from slim_amd.lora import fit_error_matrix, level_hint_from_status, fit_ns_steps
-    hint = level_hint_from_status(int(info[-2]))
-    assert hint >= 2
+    from slim_amd.lora import fit_error_matrix, level_hint_from_status, fit_ns_steps, hint_level, filter_plan
+    hint = level_hint_from_status(int(info[-2]), int(info[-3]))
+    # (the hint carries where this fit's cut sits: the second fit runs the Chebyshev-filtered iteration)
+    assert hint_level(hint) >= 2 and (hint >> 16) > 0 and filter_plan([hint]) is not None
     U, Ut, L, info2 = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread, hint=hint)
-    assert int(info2[:-2].abs().sum()) == 0 and int(info2[-1]) == 0, info2[-2:]
+    assert int(info2[:-3].abs().sum()) == 0 and int(info2[-1]) == 0, info2[-3:]
     return U, L, fit_ns_steps(spread, hint)
 
 
@@ -81,7 +82,7 @@ def test_fit_within_1e3_of_truncated_svd_full_size(ops, N, K, rank):
     E, sr = _error_matrix(ops, N, K, 100 + N % 97 + K % 89)
     outl, spread = outlier_columns(sr)
     U, Ut, L, info = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread)
-    assert int(info[:-2].abs().sum()) == 0
+    assert int(info[:-3].abs().sum()) == 0
     sv = torch.linalg.svdvals(E.float())
     excess, cond, flat = _excess(E, U[:, :rank], L[:, :rank], rank, sv)
     # and sized from its own measured spread, as the same linear of the next decoder block would be
@@ -164,7 +165,7 @@ def test_fit_within_1e3_at_llama3_70b_mlp_shapes(ops, N, K, rank):
     E, sr = _error_matrix(ops, N, K, 300 + N % 97)
     outl, spread = outlier_columns(sr, rank=rank)
     U, Ut, L, info = fit_error_matrix(E, ops.transpose(E), rank, None, outl, spread)
-    assert int(info[:-2].abs().sum()) == 0
+    assert int(info[:-3].abs().sum()) == 0
     opt, cond = _optimum_from_gram(E, rank)
     # the error in fp64 by blocks of rows (the full fp32 difference matrix would be 0.9 GB, fine, but fp64 keeps the sum exact)
     err2 = 0.0

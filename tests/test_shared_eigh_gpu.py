@@ -34,7 +34,7 @@ def test_split_fit_equals_single_call():
     for i in range(len(shapes)):
         got = ops.lowrank_fit_back(ctxs[i], d[i], e[i], Q[i], Mb[i], s=ss[i])
         torch.cuda.synchronize()
-        assert int(got["info"][..., :-2].abs().sum()) == 0
+        assert int(got["info"][..., :-3].abs().sum()) == 0
         for k in ("U", "Ut", "L"):
             assert torch.equal(got[k], refs[i][k]), (i, k)
         torch.testing.assert_close(got["S"], refs[i]["S"], rtol=0, atol=0)
@@ -64,7 +64,7 @@ def test_batched_split_fit_equals_single_call():
     d, e, Q = ops.tridiagonalize_batched(Mb)
     got = ops.lowrank_fit_back(ctx, d, e, Q, Mb, s=torch.stack(ss))
     torch.cuda.synchronize()
-    assert int(got["info"][..., :-2].abs().sum()) == 0
+    assert int(got["info"][..., :-3].abs().sum()) == 0
     for i in range(B):
         for k in ("U", "Ut", "L"):
             assert torch.equal(got[k][i], refs[i][k]), (i, k)
