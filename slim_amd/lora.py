@@ -541,7 +541,9 @@ def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations
         return ("alone", id(module)), l            # modes and ranks that do not run as a mixed-shape group
     shape = (N, K) if os.environ.get("SLIM_GROUP_BY_SHAPE", "0") == "1" else None
     hint = int(getattr(activations, "fit_level_hint", 0) or 0)
-    return (min(N, K), rf, over, fit_ns_steps(spread, hint), filter_plan([hint]) is not None, shape), l
+    # (a filtered fit sizes its orthonormalisations from the group's filter plan, not from the hint's level)
+    filtered = filter_plan([hint]) is not None
+    return (min(N, K), rf, over, fit_ns_steps(spread, 0 if filtered else hint), filtered, shape), l
 
 
 def fit_keep(c):
@@ -555,7 +557,8 @@ def add_lora_fit_front_group(ctxs, M_out, sketch_split=True):
     fit_error_matrix_front_group)."""
     for c in ctxs:
         c.touch()
-    if len({fit_ns_steps(c.spread, c.level_hint) for c in ctxs}) != 1:
+    filtered = filter_plan([c.level_hint for c in ctxs]) is not None
+    if len({fit_ns_steps(c.spread, 0 if filtered else c.level_hint) for c in ctxs}) != 1:
         raise ValueError("the layers of a group must share their Newton-Schulz depth")
     ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], [c.rank for c in ctxs],
                                                    [c.outliers for c in ctxs], ctxs[0].spread, M_out, sketch_split,

@@ -142,8 +142,9 @@ def test_add_lora_with_important_columns(ops, golden, tag):
         lv = lin.weight.data.float().cpu() * sf2
         other = torch.ones(W.shape[1], dtype=torch.bool)
         other[imp] = False
-        assert float((lv[:, other] - lv[:, other].round()).abs().max()) < 0.02
-        assert float((2 * lv[:, imp] - (2 * lv[:, imp]).round()).abs().max()) < 0.04
+        # (the weight is a bf16 tensor: a level of size 8 / sf carries a rounding of up to 8 x 2^-8)
+        assert float((lv[:, other] - lv[:, other].round()).abs().max()) < 0.035
+        assert float((2 * lv[:, imp] - (2 * lv[:, imp]).round()).abs().max()) < 0.07
         assert float(lv[:, imp].abs().max()) <= 4.01
 
 
