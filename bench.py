@@ -42,11 +42,11 @@ def synth_weight(n, k, seed, device):
     return (torch.randn(n, k, generator=g, device=device) * 0.02).to(torch.bfloat16)
 
 
-def synth_acts(nsamples, seqlen, k, seed, device):
-    """N(0,1) activations with per-column scale exp(N(0, 0.5^2)) and 4 outlier columns x30."""
+def synth_acts(nsamples, seqlen, k, seed, device, sigma=0.5, n_outliers=4, gain=30.0):
+    """N(0,1) activations with per-column scale exp(N(0, sigma^2)) and n_outliers outlier columns x gain."""
     g = torch.Generator(device=device).manual_seed(seed)
-    scale = torch.exp(torch.randn(k, generator=g, device=device) * 0.5)
-    scale[torch.randperm(k, generator=g, device=device)[:4]] *= 30.0
+    scale = torch.exp(torch.randn(k, generator=g, device=device) * sigma)
+    scale[torch.randperm(k, generator=g, device=device)[:n_outliers]] *= gain
     x = torch.empty(nsamples, seqlen, k, dtype=torch.bfloat16, device=device)
     for i in range(0, nsamples, 16):
         x[i:i + 16] = (torch.randn(min(16, nsamples - i), seqlen, k, generator=g, device=device) * scale).to(torch.bfloat16)
@@ -115,25 +115,40 @@ FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0,", "gemm_nt_small": "gemm_nt_
                  "gemm_nt_sketch": "gemm_nt_kernel<3,", "gemm_nt_big": "gemm_nt_kernel<4,", "gemm_nt_residual": "gemm_nt_kernel<5,",
                  "eigh_tridiag": "tridiag_step_kernel", "eigh_multisect": "tri_multisect_kernel", "eigh_twisted": "tri_twisted_kernel",
                  "gemm_f32": "f32_gemm_kernel", "pack24": "pack24_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
-                 "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel"}
+                 "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel",
+                 "rs_cheb": "rs_cheb_kernel", "rs_qr": "rs_qr_kernel", "rs_apply": "rs_apply_kernel", "rs_bounds": "rs_bounds_kernel",
+                 "rs_infnorm": "rs_infnorm_kernel", "rs_evals": "rs_evals_kernel"}
+
+
+TRAFFIC_FILE = "profiles/r3_pmc_traffic.json"
 
 
 def measured_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed PMC measurement of this same command
-    (profiles/r2_pmc_traffic.json, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs of
-    `bench.py --streams 1 --steps 1 --warmup 1 --no-e2e --no-cpu-baseline`), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
+    """(HBM bytes per launch of a kernel family, where the figure comes from) from the committed counter measurement of this
+    same command (TRAFFIC_FILE, made by tools/pmc_summarize.py from two `rocprofv3 --pmc` runs of
+    `bench.py --streams 1 --steps 1 --warmup 1 --no-e2e --no-cpu-baseline`), or (None, why not).  The file records the
+    fingerprint of the library sources it was measured on; a figure from other sources is not quoted."""
+    from slim_amd.build import source_fingerprint
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_FILE)
     sym = FAMILY_KERNEL.get(family)
-    if sym is None or not os.path.exists(path):
-        return None
+    if sym is None:
+        return None, f"no kernel symbol known for family {family}"
+    if not os.path.exists(path):
+        return None, f"{TRAFFIC_FILE} absent"
     try:
-        kernels = json.load(open(path))["kernels"]
+        doc = json.load(open(path))
+        if doc.get("source_fingerprint") != source_fingerprint():
+            return None, (f"{TRAFFIC_FILE} was measured on library sources {doc.get('source_fingerprint')}, "
+                          f"these are {source_fingerprint()}: not quoted")
+        kernels = doc["kernels"]
         k = kernels.get(sym) or next((v for name, v in kernels.items() if sym in name), None)
         if not k:
-            return None
-        return (k.get("read_bytes_per_launch") or 0.0) + (k.get("write_bytes_per_launch") or 0.0)
-    except Exception:
-        return None
+            return None, f"{sym} not in {TRAFFIC_FILE}"
+        return ((k.get("read_bytes_per_launch") or 0.0) + (k.get("write_bytes_per_launch") or 0.0),
+                f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on library sources "
+                f"{doc['source_fingerprint']}, commit {doc.get('commit', 'unrecorded')})")
+    except Exception as e:
+        return None, f"{TRAFFIC_FILE} unreadable: {e}"
 
 
 def main():
@@ -195,34 +210,57 @@ def main():
         raise SystemExit(f"--nsamples {args.nsamples} must be divisible by the number of ranks ({world})")
 
     # ---- resident synthetic inputs ------------------------------------------------------------------
-    lins, acts, acts_local = {}, {}, {}
+    # TWO different blocks (weights and activations from different seeds, the second with a wider spread of channel scales
+    # and other outlier channels) take turns step by step: as in the driver, where the fits of a block are sized from what
+    # the same linears of the PREVIOUS, different block measured, never from an earlier pass over the same data.
+    BLOCK_VARIANTS = [dict(sigma=0.5, n_outliers=4, gain=30.0), dict(sigma=0.56, n_outliers=6, gain=22.0)]
+    lins = {}
+    blocks = [dict(W0={}, acts={}, acts_local={}) for _ in BLOCK_VARIANTS]
     n_local = args.nsamples // world
     for i, (name, n, k, src) in enumerate(LLAMA2_7B_BLOCK):
         lin = torch.nn.Linear(k, n, bias=False, device=dev, dtype=torch.bfloat16)
         lin.weight.requires_grad_(False)
         lins[i] = lin
-        seed = 1 + ["attn", "o", "mlp", "down"].index(src)
-        if "layers" in modes and i in mine and src not in acts:
-            acts[src] = synth_acts(args.nsamples, args.seqlen, k, seed, dev)
-        if "rows" in modes and src not in acts_local:
-            # this rank's contiguous share of the calibration samples (the driver shards the block forwards the same way)
-            acts_local[src] = (acts[src][rank * n_local:(rank + 1) * n_local] if src in acts
-                               else synth_acts(n_local, args.seqlen, k, 1000 * rank + seed, dev))
-    W0 = {i: synth_weight(n, k, 100 + i, dev) for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK)}
+        for b, (blk, variant) in enumerate(zip(blocks, BLOCK_VARIANTS)):
+            seed = 1 + ["attn", "o", "mlp", "down"].index(src) + 10 * b
+            acts, acts_local = blk["acts"], blk["acts_local"]
+            if "layers" in modes and i in mine and src not in acts:
+                acts[src] = synth_acts(args.nsamples, args.seqlen, k, seed, dev, **variant)
+            if "rows" in modes and src not in acts_local:
+                # this rank's contiguous share of the calibration samples (the driver shards the block forwards the same way)
+                acts_local[src] = (acts[src][rank * n_local:(rank + 1) * n_local] if src in acts
+                                   else synth_acts(n_local, args.seqlen, k, 1000 * rank + seed, dev, **variant))
+            blk["W0"][i] = synth_weight(n, k, 100 + i + 50 * b, dev)
     block_bytes = sum(2.0 * n * k for _, n, k, _ in LLAMA2_7B_BLOCK)
+    turn = {"step": 0, "passes": 0}
+
+    def next_block():
+        blk = blocks[turn["step"] % len(blocks)]
+        turn["step"] += 1
+        return blk["W0"], blk["acts"], blk["acts_local"]
 
     from slim_amd import ops, parallel
+    import slim_amd.prune as _prune
     from slim_amd.prune import compress_linears, block_stats
+    # every pass over (a subset of) a block's linears is counted: a step whose fits were all sized well makes one, a step
+    # that had to repeat fits (hint of the other block too low, filter interval too high) makes two
+    _one_pass = _prune.compress_linears_unchecked
+
+    def _counted_pass(*a, **k):
+        turn["passes"] += 1
+        return _one_pass(*a, **k)
+    _prune.compress_linears_unchecked = _counted_pass
     from slim_amd.layerwrapper import shared_inputs, WrappedGPT
     from slim_amd.quantization.quantization import Quantizer
 
     packed = {}
     # as in the driver, where the fits of a block are sized from what the same linears of the previous block measured: here
-    # the previous step's block (the set-up steps before the warm-up fill the dictionary)
+    # the previous step's block, which is the OTHER synthetic block (the set-up steps before the warm-up fill the dictionary)
     level_hints = {}
     recipe = dict(sparsity_ratio=0.5, lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=256)
 
     def step_layers(n_streams=None):
+        W0, acts, _ = next_block()
         wrapped = {}
         # statistics pass (in the driver: hooks of the block forward).  As in a decoder block, q/k/v and gate/up
         # read the same activation tensor, whose column sums the hooks then compute once.
@@ -266,6 +304,7 @@ def main():
     def step_rows(n_streams=None):
         # statistics: every rank sums its share of the samples, the per-sample sums are gathered into sample order and
         # folded with the reference's recurrence on every rank (bit-identical to a single-GPU pass)
+        W0, _, acts_local = next_block()
         wrapped = {}
         with shared_inputs():
             for i in range(len(LLAMA2_7B_BLOCK)):
@@ -324,7 +363,9 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    passes0 = turn["passes"]
     dt = timed(step, args.steps)
+    refits_per_step = (turn["passes"] - passes0) / args.steps - 1.0
     for i in packed:
         ops.pack24_raise(int(packed[i][2].item()))
     # The same steps once more with the in-library timer on (a HIP-event pair around every launch, on the launch's own
@@ -378,7 +419,8 @@ def main():
                 return None
             # HBM bytes per launch from the counter passes over this same program on a single stream (the launches there carry
             # the same lockstep groups as here), beside the algorithmic bytes of the same launches
-            extra = {"traffic": measured_traffic(dom["name"]), "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+            traffic, traffic_source = measured_traffic(dom["name"])
+            extra = {"traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                      "avg_launch_us": dom["avg_us"], "launches": dom["count"],
                      "measured": "one extra untimed step on a single stream"}
             if dom["name"].startswith("gemm"):
@@ -400,6 +442,8 @@ def main():
                                      f"row blocks of every linear over {world} ranks, samples sharded; histogram / Rayleigh-Ritz "
                                      "all-reduce, Gram reduce, all-gather of compressed blocks" if mode == "rows" else
                                      f"whole linears over {world} ranks by cost + broadcast of the compressed linears (weights in packed form)"),
+                       "blocks_alternating": len(BLOCK_VARIANTS),
+                       "refits_per_step": refits_per_step,
                        "partition_trial_ms": {m: round(v, 2) for m, v in trial.items()} or None,
                        "compression_only_extrapolated_s": ms_per_step * 32 / 1e3,
                        "ms_per_step_with_event_timers": dt_instrumented / args.steps * 1e3},
@@ -417,9 +461,7 @@ def main():
             # including the model's own two forward passes per block that the kernel benchmark above leaves out
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from e2e_compress import run_e2e
-            for t in list(lins.values()) + list(acts.values()) + list(W0.values()):
-                del t
-            lins.clear(), acts.clear(), W0.clear(), packed.clear()
+            lins.clear(), blocks.clear(), packed.clear()
             torch.cuda.empty_cache()
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):      # the dispatcher prints what it does, as the reference's does

@@ -21,6 +21,18 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_fingerprint():
+    """Short hash over the library's sources (kernels, shared headers, the C header): measurements that are kept beside
+    the code (per-kernel HBM traffic from counter passes) carry it, and are only quoted while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "slim_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -530,8 +530,11 @@ static int rs_run(const float* M, int l, int nb, int top, const int32_t* keep_h,
     };
     {
         // ---- b >= lambda_max(M)
-        rs_infnorm_kernel<<<dim3((unsigned)((l + 15) / 16), (unsigned)nb), 256, 0, st>>>(M, l, w.scal, SC_S);
-        SLIM_LAUNCH_CHECK();
+        {
+            SLIM_PROF("rs_infnorm", st, 4.0 * nb * l * l, 2.0 * nb * l * l);
+            rs_infnorm_kernel<<<dim3((unsigned)((l + 15) / 16), (unsigned)nb), 256, 0, st>>>(M, l, w.scal, SC_S);
+            SLIM_LAUNCH_CHECK();
+        }
         {
             F32GemmArgs g = gemm(M, sM, l, l, M, sM, l, 1, l, l, w.P[0], sM, l);
             g.inv_sq_scale = w.scal + SC_S;
@@ -542,18 +545,27 @@ static int rs_run(const float* M, int l, int nb, int top, const int32_t* keep_h,
             g = gemm(w.P[1], sM, l, l, w.P[1], sM, l, 1, l, l, w.P[0], sM, l);
             CHK(slim_f32gemm_launch(g, st));
         }
-        rs_infnorm_kernel<<<dim3((unsigned)((l + 15) / 16), (unsigned)nb), 256, 0, st>>>(w.P[0], l, w.scal, SC_N3);
-        SLIM_LAUNCH_CHECK();
+        {
+            SLIM_PROF("rs_infnorm", st, 4.0 * nb * l * l, 2.0 * nb * l * l);
+            rs_infnorm_kernel<<<dim3((unsigned)((l + 15) / 16), (unsigned)nb), 256, 0, st>>>(w.P[0], l, w.scal, SC_N3);
+            SLIM_LAUNCH_CHECK();
+        }
     }
     const int lds_bounds = 2 * RS_MAX_C * RS_MAX_C * (int)sizeof(float);
     SLIM_HIP(slim_allow_dynamic_lds((const void*)rs_bounds_kernel, lds_bounds));
     // a from the leading principal block of M (and b, the estimate of the largest eigenvalue)
-    rs_bounds_kernel<<<nb, 1024, lds_bounds, st>>>(M, sM, l, keep, 1, degs[0], w.scal);
-    SLIM_LAUNCH_CHECK();
+    {
+        SLIM_PROF("rs_bounds", st, 0.0, 0.0);
+        rs_bounds_kernel<<<nb, 1024, lds_bounds, st>>>(M, sM, l, keep, 1, degs[0], w.scal);
+        SLIM_LAUNCH_CHECK();
+    }
     if (c_pad > 0) {
         // ---- the block
-        rs_init_kernel<<<dim3((unsigned)((l + 255) / 256), (unsigned)c_pad, (unsigned)nb), 256, 0, st>>>(w.Y[0], l, c_pad, keep);
-        SLIM_LAUNCH_CHECK();
+        {
+            SLIM_PROF("rs_init", st, 4.0 * nb * c_pad * l, 0.0);
+            rs_init_kernel<<<dim3((unsigned)((l + 255) / 256), (unsigned)c_pad, (unsigned)nb), 256, 0, st>>>(w.Y[0], l, c_pad, keep);
+            SLIM_LAUNCH_CHECK();
+        }
         const dim3 cheb_grid((unsigned)((l + RS_PANEL - 1) / RS_PANEL), (unsigned)nb);
         const int cheb_lds = (RS_PANEL * (l + 4) + 4 * RS_RB * 256) * (int)sizeof(float);
         SLIM_HIP(slim_allow_dynamic_lds((const void*)rs_cheb_kernel, cheb_lds));
@@ -561,38 +573,62 @@ static int rs_run(const float* M, int l, int nb, int top, const int32_t* keep_h,
         for (int r = 0; r < ndeg; ++r) {
             // Chebyshev recurrence of degree degs[r] on the rows of Y[cur]
             int y0 = cur, y1 = (cur + 1) % 3;
-            rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y0], M, l, c_pad, w.scal + SC_CA, RS_SCAL, w.Y[y0], nullptr, w.Y[y1]);
-            SLIM_LAUNCH_CHECK();
+            {
+                SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
+                rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y0], M, l, c_pad, w.scal + SC_CA, RS_SCAL, w.Y[y0], nullptr, w.Y[y1]);
+                SLIM_LAUNCH_CHECK();
+            }
             for (int k = 2; k <= degs[r]; ++k) {
                 const int y2 = 3 - y0 - y1;
-                rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y1], M, l, c_pad, w.scal + SC_CB, RS_SCAL, w.Y[y1], w.Y[y0], w.Y[y2]);
-                SLIM_LAUNCH_CHECK();
+                {
+                    SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
+                    rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y1], M, l, c_pad, w.scal + SC_CB, RS_SCAL, w.Y[y1], w.Y[y0], w.Y[y2]);
+                    SLIM_LAUNCH_CHECK();
+                }
                 y0 = y1;
                 y1 = y2;
             }
-            rs_qr_kernel<<<nb, 1024, 0, st>>>(w.Y[y1], l, c_pad, keep, w.V, w.tau);
-            SLIM_LAUNCH_CHECK();
+            {
+                SLIM_PROF("rs_qr", st, 8.0 * nb * c_pad * l, 4.0 * nb * (double)c_pad * c_pad * l);
+                rs_qr_kernel<<<nb, 1024, 0, st>>>(w.Y[y1], l, c_pad, keep, w.V, w.tau);
+                SLIM_LAUNCH_CHECK();
+            }
             if (r + 1 == ndeg) break;
             // orthonormal basis of the block, its compression of M, the tightened bound
             const int q = (y1 + 1) % 3, t1 = (y1 + 2) % 3;
-            rs_apply_kernel<<<dim3((unsigned)((c_pad + RS_WAVES - 1) / RS_WAVES), (unsigned)nb), 1024, 0, st>>>(w.V, w.tau, l, c_pad, keep, 1,
-                                                                                                            0, w.Y[q]);
-            SLIM_LAUNCH_CHECK();
-            rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[q], M, l, c_pad, w.scal + SC_ONE, RS_SCAL, nullptr, nullptr, w.Y[t1]);
-            SLIM_LAUNCH_CHECK();
+            {
+                SLIM_PROF("rs_apply", st, 0.0, 0.0);
+                rs_apply_kernel<<<dim3((unsigned)((c_pad + RS_WAVES - 1) / RS_WAVES), (unsigned)nb), 1024, 0, st>>>(w.V, w.tau, l, c_pad, keep, 1,
+                                                                                                                0, w.Y[q]);
+                SLIM_LAUNCH_CHECK();
+            }
+            {
+                SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
+                rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[q], M, l, c_pad, w.scal + SC_ONE, RS_SCAL, nullptr, nullptr, w.Y[t1]);
+                SLIM_LAUNCH_CHECK();
+            }
             CHK(slim_f32gemm_launch(gemm(w.Y[t1], sY, l, c_pad, w.Y[q], sY, l, 0, c_pad, l, w.Bm, (int64_t)c_pad * c_pad, c_pad), st));
-            rs_bounds_kernel<<<nb, 1024, lds_bounds, st>>>(w.Bm, (int64_t)c_pad * c_pad, c_pad, keep, 0, degs[r + 1], w.scal);
-            SLIM_LAUNCH_CHECK();
+            {
+                SLIM_PROF("rs_bounds", st, 0.0, 0.0);
+                rs_bounds_kernel<<<nb, 1024, lds_bounds, st>>>(w.Bm, (int64_t)c_pad * c_pad, c_pad, keep, 0, degs[r + 1], w.scal);
+                SLIM_LAUNCH_CHECK();
+            }
             cur = q;
         }
     }
     // ---- the complement basis in the eigen-solver's layout, its Rayleigh quotients
-    rs_apply_kernel<<<dim3((unsigned)((top + RS_WAVES - 1) / RS_WAVES), (unsigned)nb), 1024, 0, st>>>(w.V, w.tau, l, c_pad, keep, 0, top,
-                                                                                                  vecs);
-    SLIM_LAUNCH_CHECK();
+    {
+        SLIM_PROF("rs_apply", st, 0.0, 0.0);
+        rs_apply_kernel<<<dim3((unsigned)((top + RS_WAVES - 1) / RS_WAVES), (unsigned)nb), 1024, 0, st>>>(w.V, w.tau, l, c_pad, keep, 0, top,
+                                                                                                      vecs);
+        SLIM_LAUNCH_CHECK();
+    }
     CHK(slim_f32gemm_launch(gemm(vecs + (int64_t)(l - top) * l, sM, l, top, M, sM, l, 1, l, l, w.P[0], (int64_t)top * l, l), st));
-    rs_evals_kernel<<<dim3((unsigned)((top + 3) / 4), (unsigned)nb), 256, 0, st>>>(w.P[0], vecs, l, top, keep, w.scal, evals, info);
-    SLIM_LAUNCH_CHECK();
+    {
+        SLIM_PROF("rs_evals", st, 8.0 * nb * top * l, 2.0 * nb * top * l);
+        rs_evals_kernel<<<dim3((unsigned)((top + 3) / 4), (unsigned)nb), 256, 0, st>>>(w.P[0], vecs, l, top, keep, w.scal, evals, info);
+        SLIM_LAUNCH_CHECK();
+    }
     return SLIM_OK;
 }
 
@@ -616,7 +652,6 @@ extern "C" int slim_ritz_split_f32_batched(const float* M, int l, int batch, int
     SLIM_REQUIRE(((uintptr_t)M % 16) == 0 && ((uintptr_t)vecs % 16) == 0 && ((uintptr_t)workspace % 256) == 0,
                  "slim_ritz_split_f32_batched: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
-    SLIM_PROF("ritz_split", stream, 0.0, 0.0);
     for (int b0 = 0; b0 < batch; b0 += RS_MAX_BATCH) {
         const int nb = batch - b0 < RS_MAX_BATCH ? batch - b0 : RS_MAX_BATCH;
         CHK(rs_run(M + (int64_t)b0 * l * l, l, nb, top, keep + b0, degs, n_rounds, vecs + (int64_t)b0 * l * l, evals + (int64_t)b0 * l,

@@ -41,22 +41,22 @@ FIT_EXACT_FINAL = os.environ.get("SLIM_FIT_EXACT_FINAL", "0") == "1"
 FIT_SKETCH_SPLIT = os.environ.get("SLIM_FIT_SKETCH_SPLIT", "1") == "1"
 
 
-def fit_ns_steps(spread, hint=0):
+def fit_ns_steps(spread, hint=0, floor=0):
     """The `ns_steps` argument of slim_lowrank_fit.  Bits 0-7: log2 of the conditioning the fit's Newton-Schulz
     orthonormalisations are sized for, from the spread max(s) / median(s) of the saliency scales that are left after the outlier columns
     have been split off.  The error matrix is (benign matrix) x diag(s): its largest singular values come from the columns
     with the largest scale, the bulk from the typical ones, so the conditioning of an iterate inside the leading subspace
     is of the order of the spread (measured: about a third of it, so half the spread is assumed).  The fit checks the
     assumption against the spectrum it finds (status word SLIM_FIT_INFO_COND_WORD) and the driver repeats a fit whose
-    estimate was too low with FIT_COND_FLOOR raised (prune.compress_linears).
-    Bits 8-15: `hint`, the level a similar fit measured (level_hint_from_status), or 0; ignored while FIT_COND_FLOOR is
-    raised (a repeated fit runs on the estimate alone)."""
+    estimate was too low with `floor`, a lower bound of the level, set to what the fit reported (prune.compress_linears).
+    Bits 8-15: `hint`, the level a similar fit measured (level_hint_from_status), or 0; ignored when a floor is given (a
+    repeated fit runs on the estimate alone)."""
     import math
     if os.environ.get("SLIM_FIT_COND_E"):          # tuning aid: fixed value
         return int(os.environ["SLIM_FIT_COND_E"])
-    level = int(min(6, max(1, FIT_COND_FLOOR, math.ceil(math.log2(max(float(spread) / 2.0, 1.0))))))
+    level = int(min(6, max(1, int(floor), math.ceil(math.log2(max(float(spread) / 2.0, 1.0))))))
     hint = hint_level(hint)
-    if hint and not FIT_COND_FLOOR and FIT_LEVEL_HINTS:
+    if hint and not floor and FIT_LEVEL_HINTS:
         level |= int(min(12, max(2, hint))) << 8
     return level
 
@@ -92,11 +92,11 @@ FIT_FILTER_ROUNDS = int(os.environ.get("SLIM_FIT_FILTER_ROUNDS", "3"))
 FIT_FILTER_MARGIN = float(os.environ.get("SLIM_FIT_FILTER_MARGIN", "0.8"))
 
 
-def filter_plan(hints):
+def filter_plan(hints, floor=0):
     """(ratios per member, bits, n_iter) of the filtered iteration for fits with these packed hints, or None when any of
-    them carries no ratio (or the filter is off, or the fits are being repeated)."""
+    them carries no ratio (or the filter is off, or the fits are being repeated: floor > 0)."""
     import math
-    if not FIT_FILTER or FIT_COND_FLOOR or FIT_CHOLESKY_QR or FIT_EXACT_FINAL or not FIT_LEVEL_HINTS:
+    if not FIT_FILTER or floor or FIT_CHOLESKY_QR or FIT_EXACT_FINAL or not FIT_LEVEL_HINTS:
         return None
     hints = [int(h) for h in hints]
     if not hints or any((h >> 16) <= 0 for h in hints):
@@ -105,11 +105,8 @@ def filter_plan(hints):
     # largest eigenvalue over the interval's end: the measured spread (word / 4 = log2), 5 % slack, the margin
     kappa = max(2.0 ** (((h >> 8) & 0xff) / 4.0) for h in hints) * 1.05 / FIT_FILTER_MARGIN      # (the cut lies above `lo`)
     bits = int(math.ceil(math.log2(2.0 * (2.0 * kappa - 1.0) ** 2 - 1.0) + 0.5))
+    bits += bits & 1            # (even: fits in lockstep must agree on it, see planned_fit_group, and coarser classes agree more often)
     return ratios, max(2, min(bits, 12)), 2 * FIT_FILTER_ROUNDS - 1
-
-
-# lower bound of fit_ns_steps; raised by the driver while it repeats fits whose conditioning was underestimated
-FIT_COND_FLOOR = 0
 
 
 # Columns of the error matrix whose saliency scale exceeds OUTLIER_RATIO x the median are split off and
@@ -161,17 +158,27 @@ def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, i
 
 # The Rayleigh-Ritz step of a fit as a search for the small subspace to drop (ops.ritz_split) instead of an
 # eigen-decomposition of the l x l matrix (a chain of l dependent launches); SLIM_FIT_RITZ_SPLIT=0: the eigen-solver.
-# A fit that is being repeated (FIT_COND_FLOOR raised: its spectrum was wider than expected) takes the eigen-solver.
+# A fit that is being repeated (floor > 0: its spectrum was wider than expected) takes the eigen-solver.
 FIT_RITZ_SPLIT = os.environ.get("SLIM_FIT_RITZ_SPLIT", "1") == "1"
 
 
-def rayleigh_ritz(Mg, top, keeps):
+def ritz_split_applies(l, drop, floor=0):
+    """Whether the Rayleigh-Ritz step of a fit with subspace dimension l that drops `drop` directions goes through
+    ops.ritz_split.  Only while the dropped subspace is a small part of the whole (at most a quarter: l = 576, 64 to 80
+    dropped on 7B / 13B-shaped layers; l = 320, 64 dropped at OPT-125m's): it is found by block iteration without
+    oversampling, which loses accuracy when most of the subspace is to be dropped (measured on 256 x 512 layers, 71 of 96
+    dropped: total error +0.8 %), and a small l makes the eigen-solver's chain short anyway."""
+    return bool(FIT_RITZ_SPLIT and not floor and 4 * drop <= l and ops.ritz_split_supported(l, drop))
+
+
+def rayleigh_ritz(Mg, top, keeps, floor=0):
     """The eigen-stage between the two halves of a fit for B problems: Mg [B, l, l] (destroyed by the eigen-solver) ->
     (evals [B, l], vecs [B, l, l], info int32 [B]) as lowrank_fit_back / _group take them with e = Q = None.  keeps: per
-    problem the number of directions the caller will use (rank minus split-off columns)."""
+    problem the number of directions the caller will use (rank minus split-off columns).  floor > 0 (a repeated fit): the
+    eigen-solver."""
     B, l, _ = Mg.shape
     keeps = [min(int(k), int(top)) for k in keeps]
-    if FIT_RITZ_SPLIT and not FIT_COND_FLOOR and ops.ritz_split_supported(l, max(l - k for k in keeps)):
+    if ritz_split_applies(l, max(l - k for k in keeps), floor):
         evals, vecs, info = (lambda v, e, i: (e, v, i))(*ops.ritz_split(Mg, top, keeps))
         return evals, vecs, info
     d, e, Q = ops.tridiagonalize_batched(Mg)
@@ -179,7 +186,7 @@ def rayleigh_ritz(Mg, top, keeps):
     return d, Mg, info
 
 
-def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
+def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0, floor=0):
     """Rank-`rank` factors of the error matrix E [N, K] (Et its transpose): U [N, r8], Ut [r8, N], L [K, r8]
     with r8 = rank rounded up to a multiple of 8 and the columns >= rank zero (the MFMA products that consume
     the factors need a reduction length that is a multiple of 8; callers slice [:, :rank] for the adapters).
@@ -197,26 +204,25 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
     UO = Ct = info_o = None
     if t:
         E, UO, Ct, info_o, Et = deflate_outliers(E, Et, outliers)
-    if (FIT_RITZ_SPLIT and not FIT_COND_FLOOR and not (FIT_CHOLESKY_QR or FIT_LIBRARY_EIGH or FIT_EXACT_FINAL)
-            and l < min(N, K) and ops.ritz_split_supported(l, l - (rank - t))):
-        # front half, the split of the Rayleigh-Ritz matrix, back half
+    if not (FIT_CHOLESKY_QR or FIT_LIBRARY_EIGH or FIT_EXACT_FINAL) and l < min(N, K):
+        # front half (filtered when the hint carries a ratio), the Rayleigh-Ritz step (rayleigh_ritz), back half
         M = torch.empty(1, l, l, dtype=torch.float32, device=E.device)
-        plan = filter_plan([hint])
+        plan = filter_plan([hint], floor)
         ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
-        ctx = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M[0], **_fit_kwargs(spread, True, hint))
-        evals, vecs, info = rayleigh_ritz(M, rf, [rank - t])
+        ctx = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M[0], **_fit_kwargs(spread, True, hint, floor))
+        evals, vecs, info = rayleigh_ritz(M, rf, [rank - t], floor)
         fit = ops.lowrank_fit_back(ctx, evals, None, None, vecs, s=s, tail_info=info)
     else:
         fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
-                              ns_steps=fit_ns_steps(spread, hint), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
+                              ns_steps=fit_ns_steps(spread, hint, floor), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
                               sketch_split=FIT_SKETCH_SPLIT)
     return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
 
 
-def _fit_kwargs(spread, sketch_split=True, hint=0):
+def _fit_kwargs(spread, sketch_split=True, hint=0, floor=0):
     return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL,
                                                     FIT_SKETCH_SPLIT and sketch_split),
-                ns_steps=fit_ns_steps(spread, hint))
+                ns_steps=fit_ns_steps(spread, hint, floor))
 
 
 def fit_plan(N, K, rank, outliers=None):
@@ -232,7 +238,7 @@ def fit_plan(N, K, rank, outliers=None):
     return rf, over, ops.fit_subspace(N, K, rf, over), t
 
 
-def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None):
+def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None, floor=0):
     """fit_error_matrix up to the Rayleigh-Ritz matrix of its randomized fit (written to M_out [l, l], l from fit_plan), so
     that the eigenproblems of several layers can share one batched tridiagonalisation.  Returns the state that
     fit_error_matrix_back completes."""
@@ -243,9 +249,10 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
     p = dict(N=N, K=K, rank=rank, t=t, UO=None, Ct=None, info_o=None)
     if t:
         E, Et, p["UO"], p["Ct"], p["info_o"] = deflated if deflated is not None else deflated_pair(E, Et, outliers)
-    plan = filter_plan([hint]) if l < min(N, K) else None
+    plan = filter_plan([hint], floor) if l < min(N, K) else None
     ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
-    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M_out, **_fit_kwargs(spread, sketch_split, hint))
+    p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M_out,
+                                     **_fit_kwargs(spread, sketch_split, hint, floor))
     return p
 
 
@@ -255,7 +262,8 @@ def deflated_pair(E, Et, outliers):
     return E2, E2t, UO, Ct, info_o
 
 
-def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None, hints=None):
+def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch_split=True, hint=0, deflated=None, hints=None,
+                                 floor=0):
     """fit_error_matrix_front for B layers in lockstep.  Their shapes, ranks and deflation sets may differ as long as the
     short dimension min(N, K) and the fit's plan (rank asked of the randomized fit, oversampling, subspace dimension, see
     fit_plan) agree: the subspace iteration then runs as one batched chain.  M_out [B, l, l].  Every member's result
@@ -281,10 +289,10 @@ def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch
         Eds.append(E)
         Etds.append(Et)
         p["members"].append(m)
-    plan = filter_plan(hints if hints is not None else [hint] * B)
+    plan = filter_plan(hints if hints is not None else [hint] * B, floor)
     ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
     p["ctx"] = ops.lowrank_fit_front_group(Eds, Etds, rf, over, plan[2] if plan else fit_iters(l), M_out,
-                                           **_fit_kwargs(spread, sketch_split, hint))
+                                           **_fit_kwargs(spread, sketch_split, hint, floor))
     return p
 
 
@@ -465,6 +473,7 @@ def add_lora_prepare(module, W_mask, rank_ratio=0.01, slim_lora=False, activatio
         outliers, spread = None, 1.0
     c.outliers, c.spread = outliers, spread
     c.level_hint = int(getattr(activations, "fit_level_hint", 0) or 0)
+    c.cond_floor = int(getattr(activations, "fit_cond_floor", 0) or 0)       # > 0: this fit is being repeated
     c.fit = None
     c.deflated = None
     return c
@@ -502,6 +511,7 @@ def add_lora_prepare_fused(module, prune_n, prune_m, rank_ratio, slim_lora, acti
     c.W_mask, c.E, c.Et = out["mask"], out["E"], out["Et"]
     c.s = out["s"] if use_slim else None
     c.level_hint = int(getattr(activations, "fit_level_hint", 0) or 0)
+    c.cond_floor = int(getattr(activations, "fit_cond_floor", 0) or 0)       # > 0: this fit is being repeated
     c.fit = None
     c.deflated = out["deflated"]
     return c
@@ -541,9 +551,12 @@ def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations
         return ("alone", id(module)), l            # modes and ranks that do not run as a mixed-shape group
     shape = (N, K) if os.environ.get("SLIM_GROUP_BY_SHAPE", "0") == "1" else None
     hint = int(getattr(activations, "fit_level_hint", 0) or 0)
-    # (a filtered fit sizes its orthonormalisations from the group's filter plan, not from the hint's level)
-    filtered = filter_plan([hint]) is not None
-    return (min(N, K), rf, over, fit_ns_steps(spread, 0 if filtered else hint), filtered, shape), l
+    floor = int(getattr(activations, "fit_cond_floor", 0) or 0)
+    # (a filtered fit sizes its orthonormalisations from its filter plan, not from the hint's level.  Everything that shapes a
+    # member's arithmetic is part of the key, so that a layer's result does not depend on which layers share its chain:
+    # several ranks dealing the layers of a block among themselves produce what one rank does)
+    plan = filter_plan([hint], floor)
+    return (min(N, K), rf, over, fit_ns_steps(spread, 0 if plan else hint, floor), plan[1] if plan else 0, shape), l
 
 
 def fit_keep(c):
@@ -557,12 +570,13 @@ def add_lora_fit_front_group(ctxs, M_out, sketch_split=True):
     fit_error_matrix_front_group)."""
     for c in ctxs:
         c.touch()
-    filtered = filter_plan([c.level_hint for c in ctxs]) is not None
-    if len({fit_ns_steps(c.spread, 0 if filtered else c.level_hint) for c in ctxs}) != 1:
+    floor = max(c.cond_floor for c in ctxs)
+    filtered = filter_plan([c.level_hint for c in ctxs], floor) is not None
+    if len({fit_ns_steps(c.spread, 0 if filtered else c.level_hint, floor) for c in ctxs}) != 1:
         raise ValueError("the layers of a group must share their Newton-Schulz depth")
     ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], [c.rank for c in ctxs],
                                                    [c.outliers for c in ctxs], ctxs[0].spread, M_out, sketch_split,
-                                                   ctxs[0].level_hint, [c.deflated for c in ctxs], [c.level_hint for c in ctxs])
+                                                   ctxs[0].level_hint, [c.deflated for c in ctxs], [c.level_hint for c in ctxs], floor)
 
 
 def add_lora_fit_back_group(ctxs, d, e, Q, vecs, tail_info=None):
@@ -580,7 +594,8 @@ def add_lora_fit_front(c, M_out, sketch_split=True):
     """Second phase, first half (see fit_error_matrix_front).  sketch_split=False: the caller runs several fits side by
     side, which fills the chip without cutting the sketch products along their reduction."""
     c.touch()
-    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out, sketch_split, c.level_hint, c.deflated)
+    c.pending = fit_error_matrix_front(c.E, c.Et, c.rank, c.outliers, c.spread, M_out, sketch_split, c.level_hint, c.deflated,
+                                       c.cond_floor)
 
 
 def add_lora_fit_back(c, d, e, Q, vecs, tail_info=None):
@@ -597,7 +612,8 @@ def add_lora_fit(ctxs):
         # merged adapters (separate_lora=False) divide the product, not the factor, by sqrt(scaler_row); pruned
         # adapters are pruned and re-fitted before that division (lora.py:185-195)
         scaled_in_fit = c.separate and not c.prune_lora
-        c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread, c.level_hint)
+        c.fit = fit_error_matrix(c.E, c.Et, c.rank, c.s if scaled_in_fit else None, c.outliers, c.spread, c.level_hint,
+                                 c.cond_floor)
         if c.prune_lora:
             U, Ut, L, info = c.fit
             c.lora_left_mask = prune_and_optimize_lora(L, Ut, PRUNE_LORA_ITERS)

@@ -384,6 +384,7 @@ def compress_linears(items, dev, *args, level_hints=None, **kwargs):
     keys = [(name, tuple(lin.weight.shape)) for name, lin, _ in items]
     for key, (_, _, wrapped) in zip(keys, items):
         wrapped.fit_level_hint = level_hints.get(key, 0) if level_hints is not None else 0
+        wrapped.fit_cond_floor = 0
     compress_linears_unchecked(items, dev, *args, **kwargs)
     found = {}
     again = check_fit_status(items, found)
@@ -392,13 +393,10 @@ def compress_linears(items, dev, *args, level_hints=None, **kwargs):
             _reset_linear(items[i][1], originals[i])
             if masks[i] is not None:
                 items[i][1].weight.mask = masks[i]
-        floor = _lora.FIT_COND_FLOOR
-        _lora.FIT_COND_FLOOR = max(again.values())
         order = sorted(again)
-        try:
-            compress_linears_unchecked([items[i] for i in order], dev, *args, **kwargs)
-        finally:
-            _lora.FIT_COND_FLOOR = floor
+        for i in order:                     # the repeated fits are sized for the widest spectrum any of them reported
+            items[i][2].fit_cond_floor = max(again.values())
+        compress_linears_unchecked([items[i] for i in order], dev, *args, **kwargs)
         refound = {}
         check_fit_status([items[i] for i in order], refound)      # failures still raise; a second request is not followed
         found.update({order[j]: w for j, w in refound.items()})
@@ -578,7 +576,8 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                     fit_front(g)
                     mark("front")
                     Mg = Mb[l][b0:b0 + len(members)]
-                    evals, vecs, tail = _lora.rayleigh_ritz(Mg, fit_rank(g), [_lora.fit_keep(ctxs[i]) for i in members])
+                    evals, vecs, tail = _lora.rayleigh_ritz(Mg, fit_rank(g), [_lora.fit_keep(ctxs[i]) for i in members],
+                                                            max(ctxs[i].cond_floor for i in members))
                     mark("rayleigh_ritz")
                     fit_back(g, evals, None, None, vecs, tail)
                     mark("back")
@@ -603,7 +602,8 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
                 l = where[g][0]
                 top[l] = max(top.get(l, 0), fit_rank(g))
                 keeps.setdefault(l, []).extend(_lora.fit_keep(ctxs[i]) for i in fit_groups[g][1])
-            rr = {l: _lora.rayleigh_ritz(Mb[l], top[l], keeps[l]) for l in sorted(Mb)}
+            floor = max(c.cond_floor for c in ctxs)
+            rr = {l: _lora.rayleigh_ritz(Mb[l], top[l], keeps[l], floor) for l in sorted(Mb)}
 
             def back(g):
                 members = fit_groups[g][1]

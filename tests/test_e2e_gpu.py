@@ -205,7 +205,7 @@ def test_masks_and_first_pass_codes_bit_exact_on_reference_statistics(golden, ta
             assert torch.equal(codes.cpu(), g13[p + "codes1"]), p
 
 
-def _exact_svd_fit(E, Et, rank, s, outliers=None, spread=1.0, hint=0):
+def _exact_svd_fit(E, Et, rank, s, outliers=None, spread=1.0, hint=0, floor=0):
     """Test-only stand-in for slim_amd.lora.fit_error_matrix: the factors of slim/lora.py:172-195 from a full SVD
     (torch, on the GPU), with the reference's bf16 rounding sequence."""
     U, S, V = torch.svd(E.float())

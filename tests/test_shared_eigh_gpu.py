@@ -145,9 +145,11 @@ def test_underestimated_conditioning_is_detected_and_the_fit_repeated():
         wrapped.nsamples = 8
         P.block_stats([wrapped])
         real, real_steps = P.compress_linears_unchecked, LORA.fit_ns_steps
-        P.compress_linears_unchecked = lambda *a, **k: (calls.append(LORA.FIT_COND_FLOOR), real(*a, **k))[1]
+        # (what is recorded per pass: the level the driver asks the repeated fits to be sized for, 0 on the first pass)
+        P.compress_linears_unchecked = lambda items, *a, **k: (calls.append(max(w.fit_cond_floor for _, _, w in items)),
+                                                               real(items, *a, **k))[1]
         if cond_e is not None:
-            LORA.fit_ns_steps = lambda spread, hint=0: max(cond_e, LORA.FIT_COND_FLOOR)
+            LORA.fit_ns_steps = lambda spread, hint=0, floor=0: max(cond_e, floor)
         try:
             P.compress_linears([("lin", lin, wrapped)], torch.device("cuda", 0), 2, 4, quantizer=Quantizer("weight", num_bits=4, slim_quant=True),
                                lora_rank=0.1, slim_lora=True, quantize_lora=True, lora_tile_size=128, level_hints=hints)
@@ -174,3 +176,16 @@ def test_underestimated_conditioning_is_detected_and_the_fit_repeated():
     # and with the hint it left behind: one pass, as good
     err_next, calls_next, word_next = run(None, hints)
     assert len(calls_next) == 1 and word_next == 0 and err_next <= err_wide * (1 + 1e-3)
+    # a hint whose cut sits too high for this layer (a previous block with a spectrum that ends much higher): the filtered
+    # iteration damps directions it should keep, the fit notices (its own cut lies below the interval's end), is repeated
+    # unfiltered, and leaves its own measurement behind
+    good = hints[("lin", (N, K))]
+    assert LORA.filter_plan([good]) is not None
+    too_high = (good & 0xffff) | (min(int((good >> 16) * 1.6), 65535) << 16)
+    hints2 = {("lin", (N, K)): too_high}
+    err_f, calls_f, _ = run(None, hints2)
+    print(f"filter interval too high: {err_f:.4f} ({len(calls_f)} passes), ratio left behind {(hints2[('lin', (N, K))] >> 16) / 2048:.3f} "
+          f"(was given {(too_high >> 16) / 2048:.3f}, measured before {(good >> 16) / 2048:.3f})")
+    assert len(calls_f) == 2 and calls_f[1] >= 1
+    assert err_f <= err_wide * (1 + 1e-3)
+    assert abs((hints2[("lin", (N, K))] >> 16) / (good >> 16) - 1) < 0.1

@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 counter-collection runs of the same single-threaded command (one
 with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE):
 
-    python tools/pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <calib bytes>
+    python tools/pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <calib bytes> [commit]
 
 The counters' unit is calibrated, not assumed: the statistics kernel (colsumsq_kernel) streams exactly 2 bytes per
 activation element with 16-byte loads, so <calib bytes> = the bytes it read over the whole run (bench.py, one step:
@@ -10,6 +10,7 @@ streaming reads (on gfx950 these are tallied at half their size, which the calib
 taken in its documented unit of 1024 bytes.  Output: read / write bytes per launch for every kernel."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -32,7 +33,12 @@ def main():
     # "<bytes>/launch": the average bytes per launch of the calibration kernel instead of the run's total
     known = float(sys.argv[4][:-7]) * fetch[cal_name][0] if sys.argv[4].endswith("/launch") else float(sys.argv[4])
     read_unit = known / fetch[cal_name][1]
-    out = {"calibration": {"kernel": cal_name, "known_bytes_total": known, "counter_total": fetch[cal_name][1],
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from slim_amd.build import source_fingerprint
+    # the library sources the counters were collected on (run this right after the counter passes, on the same tree) and,
+    # when given, the commit that holds them: bench.py quotes these figures only while the fingerprint still matches
+    out = {"source_fingerprint": source_fingerprint(), "commit": sys.argv[5] if len(sys.argv) > 5 else None,
+           "calibration": {"kernel": cal_name, "known_bytes_total": known, "counter_total": fetch[cal_name][1],
                            "bytes_per_fetch_unit": read_unit, "bytes_per_write_unit": 1024.0}, "kernels": {}}
     for name in sorted(set(fetch) | set(write)):
         n = fetch.get(name, write.get(name))[0]
