@@ -39,10 +39,10 @@ extern "C" {
  * drops, mean = trace / dimension of the Gram matrix of E: where the cut sits in the spectrum.  A caller that fits a similar
  * matrix next may hand about 0.9 x word / 2048 to slim_lowrank_fit_set_filter. */
 #define SLIM_FIT_INFO_RATIO_WORD 61
-#define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: orthonormalise by Cholesky-QR (rocSOLVER) instead of Newton-Schulz */
-#define SLIM_FIT_TWO_SIDED 2    /* alternating subspace iteration on E and E^T (two products with the N x K matrix and two
-                                 * orthonormalisations per iteration) instead of the iteration on the Gram matrix of E */
-#define SLIM_FIT_EXACT_FINAL 8  /* last basis finished by Cholesky-QR (rocSOLVER) instead of the fp32 inverse-square-root polish */
+#define SLIM_FIT_CHOLESKY_QR 1 /* slim_lowrank_fit flags: a comparison mode -- the alternating subspace iteration on E and E^T
+                                * (two products with the N x K matrix and two orthonormalisations per iteration) with every
+                                * basis orthonormalised by Cholesky-QR (rocSOLVER) instead of the iteration on the Gram
+                                * matrix of E with Newton-Schulz orthonormalisations */
 #define SLIM_FIT_NO_SKETCH_SPLIT 16 /* the caller runs several fits side by side: do not cut the sketch products along the
                                      * reduction (by default the ones that under-fill the chip are) and cut the Gram products
                                      * into at most two slices */

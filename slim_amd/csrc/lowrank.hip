@@ -677,12 +677,9 @@ static int build_ns_steps(int cond_e, bool final_pass, NsStep* out) {
 static int orth(Pair* bufs, int cur, int64_t rows, int l, bool final_pass, int flags, int cond_e, FitWs& w, int info_idx,
                 void* stream, int* out_idx) {
     NsStep steps[NS_MAX_STEPS];
-    if ((flags & SLIM_FIT_CHOLESKY_QR) || (final_pass && (flags & SLIM_FIT_EXACT_FINAL))) {
-        int mid = cur;
-        if (!(flags & SLIM_FIT_CHOLESKY_QR))   // exact final: condition the basis first, then factorise
-            CHK(ns_orth(bufs, cur, rows, l, steps, build_ns_steps(cond_e, false, steps), w, stream, &mid));
-        const int nxt = (mid + 1) % 3;
-        CHK(cholesky_qr(bufs[mid], bufs[nxt], rows, l, w, info_idx, stream));
+    if (flags & SLIM_FIT_CHOLESKY_QR) {
+        const int nxt = (cur + 1) % 3;
+        CHK(cholesky_qr(bufs[cur], bufs[nxt], rows, l, w, info_idx, stream));
         *out_idx = nxt;
         return SLIM_OK;
     }
@@ -762,7 +759,7 @@ static int fit_impl(int phase, const void* E, const void* Et, int batch, int64_t
     hipStream_t st = (hipStream_t)stream;
     FitWs w = fit_ws((char*)workspace, batch, N, K, l);
     if (phase != FIT_BACK) SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
-    if (phase == FIT_BACK ? (*state & FIT_STATE_GRAM) != 0 : !(flags & (SLIM_FIT_TWO_SIDED | SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL))) {
+    if (phase == FIT_BACK ? (*state & FIT_STATE_GRAM) != 0 : !(flags & SLIM_FIT_CHOLESKY_QR)) {
         int inner = state ? (*state & ~FIT_STATE_GRAM) : 0;
         const int cond = ns_levels_clamped(ns_steps);
         int rc = gram_fit_impl(phase, E, Et, batch, N, K, r, l, n_iter, seed, flags, cond, s, U, Ut, L, S, info_out, w, stream, M_ext,
@@ -1534,7 +1531,7 @@ extern "C" int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_it
     const int cond = ns_levels_clamped(cond_e);
     int a = 0, ninfo = 0;
     // (no filter on this path: the caller's matrix is only read)
-    CHK(gram_iterate(w.A, (bf16_t*)C16, Dm * Dm, 1, Dm, l, n_iter, seed, flags & ~(SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL),
+    CHK(gram_iterate(w.A, (bf16_t*)C16, Dm * Dm, 1, Dm, l, n_iter, seed, flags & ~SLIM_FIT_CHOLESKY_QR,
                      cond, w, w.sketch_slab, (int64_t)SKETCH_MAX_SPLITS * l * Dm, stream, &a, &ninfo));
     const size_t bytes = (size_t)Dm * l * sizeof(bf16_t);
     SLIM_HIP(hipMemcpyAsync(P, w.A[a].X, bytes, hipMemcpyDeviceToDevice, st));
@@ -1679,7 +1676,7 @@ extern "C" int slim_lowrank_fit_front_group(const void* const* E, const void* co
     SLIM_REQUIRE(E && Et && M_out && state && workspace, "slim_lowrank_fit_front_group: null pointer");
     SLIM_REQUIRE(r > 0 && l >= r && l < Dm && l % 8 == 0 && r % 8 == 0 && n_iter >= 0, "slim_lowrank_fit_front_group: bad sizes");
     SLIM_REQUIRE(2 * (n_iter + 1) + 1 <= SLIM_FIT_INFO_WORDS / 2, "slim_lowrank_fit_front_group: too many iterations");
-    SLIM_REQUIRE(!(flags & (SLIM_FIT_TWO_SIDED | SLIM_FIT_CHOLESKY_QR | SLIM_FIT_EXACT_FINAL)),
+    SLIM_REQUIRE(!(flags & SLIM_FIT_CHOLESKY_QR),
                  "slim_lowrank_fit_front_group: only the Gram-side iteration runs as a mixed-shape group");
     SLIM_REQUIRE(workspace_bytes >= fit_ws(nullptr, batch, Dxm, Dm, l).total, "slim_lowrank_fit_front_group: workspace too small");
     hipStream_t st = (hipStream_t)stream;

@@ -35,8 +35,6 @@ FIT_CHOLESKY_QR = os.environ.get("SLIM_FIT_CHOLESKY_QR", "0") == "1"
 
 # Rayleigh-Ritz eigenproblem through rocSOLVER syevd instead of the library's own one-launch-per-column solver
 FIT_LIBRARY_EIGH = os.environ.get("SLIM_FIT_LIBRARY_EIGH", "0") == "1"
-# last basis before the Rayleigh-Ritz step finished by Cholesky-QR (rocSOLVER potrf + trtri) instead of the fp32 polish
-FIT_EXACT_FINAL = os.environ.get("SLIM_FIT_EXACT_FINAL", "0") == "1"
 # split-K for the sketch products whose tile grid under-fills the chip
 FIT_SKETCH_SPLIT = os.environ.get("SLIM_FIT_SKETCH_SPLIT", "1") == "1"
 
@@ -96,7 +94,7 @@ def filter_plan(hints, floor=0):
     """(ratios per member, bits, n_iter) of the filtered iteration for fits with these packed hints, or None when any of
     them carries no ratio (or the filter is off, or the fits are being repeated: floor > 0)."""
     import math
-    if not FIT_FILTER or floor or FIT_CHOLESKY_QR or FIT_EXACT_FINAL or not FIT_LEVEL_HINTS:
+    if not FIT_FILTER or floor or FIT_CHOLESKY_QR or not FIT_LEVEL_HINTS:
         return None
     hints = [int(h) for h in hints]
     if not hints or any((h >> 16) <= 0 for h in hints):
@@ -204,7 +202,7 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0, floor=0)
     UO = Ct = info_o = None
     if t:
         E, UO, Ct, info_o, Et = deflate_outliers(E, Et, outliers)
-    if not (FIT_CHOLESKY_QR or FIT_LIBRARY_EIGH or FIT_EXACT_FINAL) and l < min(N, K):
+    if not (FIT_CHOLESKY_QR or FIT_LIBRARY_EIGH) and l < min(N, K):
         # front half (filtered when the hint carries a ratio), the Rayleigh-Ritz step (rayleigh_ritz), back half
         M = torch.empty(1, l, l, dtype=torch.float32, device=E.device)
         plan = filter_plan([hint], floor)
@@ -214,13 +212,13 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0, floor=0)
         fit = ops.lowrank_fit_back(ctx, evals, None, None, vecs, s=s, tail_info=info)
     else:
         fit = ops.lowrank_fit(E, Et, rf, over, fit_iters(l), seed=FIT_SEED, s=s, cholesky_qr=FIT_CHOLESKY_QR,
-                              ns_steps=fit_ns_steps(spread, hint, floor), library_eigh=FIT_LIBRARY_EIGH, exact_final=FIT_EXACT_FINAL,
+                              ns_steps=fit_ns_steps(spread, hint, floor), library_eigh=FIT_LIBRARY_EIGH,
                               sketch_split=FIT_SKETCH_SPLIT)
     return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
 
 
 def _fit_kwargs(spread, sketch_split=True, hint=0, floor=0):
-    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_LIBRARY_EIGH, FIT_EXACT_FINAL,
+    return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_LIBRARY_EIGH,
                                                     FIT_SKETCH_SPLIT and sketch_split),
                 ns_steps=fit_ns_steps(spread, hint, floor))
 
@@ -547,7 +545,7 @@ def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations
     use_slim = bool(slim_lora) and not activations.has_zero
     rf, over, _, t = fit_plan(N, K, rank, activations.outliers if use_slim else None)
     spread = activations.scale_spread if use_slim else 1.0
-    if FIT_CHOLESKY_QR or FIT_EXACT_FINAL or (t == 0 and rf != _round_up8(rank)):
+    if FIT_CHOLESKY_QR or (t == 0 and rf != _round_up8(rank)):
         return ("alone", id(module)), l            # modes and ranks that do not run as a mixed-shape group
     shape = (N, K) if os.environ.get("SLIM_GROUP_BY_SHAPE", "0") == "1" else None
     hint = int(getattr(activations, "fit_level_hint", 0) or 0)

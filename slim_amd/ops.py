@@ -378,7 +378,7 @@ def orthonormalize(X, Xt=None, ns_quintic=2, ns_cubic=3, cholesky_qr=False):
 
 
 def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False, ns_steps=0,
-                library_eigh=False, exact_final=False, sketch_split=True):
+                library_eigh=False, sketch_split=True):
     """Leading-r factors of E [N, K]: returns dict(U [N,r], Ut [r,N], L [K,r], S [r], info).
     E [B, N, K] (with Et [B, K, N], s [B, K]) runs B fits of identical shape in lockstep and returns
     tensors with a leading batch dimension."""
@@ -405,7 +405,7 @@ def lowrank_fit(E, Et, r, oversample, n_iter, seed=0, s=None, cholesky_qr=False,
     S = torch.empty(*lead, r, dtype=torch.float32, device=dev)
     info = torch.empty(*lead, 64, dtype=torch.int32, device=dev)
     ws = _ws(_lib.query("slim_lowrank_fit_batched_workspace_bytes", B, N, K, l), dev)
-    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, fit_flags(cholesky_qr, library_eigh, exact_final, sketch_split),
+    _lib.call("slim_lowrank_fit_batched", _p(E), _p(Et), B, N, K, r, l, n_iter, seed, fit_flags(cholesky_qr, library_eigh, sketch_split),
               int(ns_steps), _p(s), _p(U), _p(Ut), _p(L), _p(S), _p(info), _p(ws), ws.numel(), _stream())
     return dict(U=U, Ut=Ut, L=L, S=S, info=info, l=l)
 
@@ -427,8 +427,8 @@ def lora_prune_optimize(L32, R32, L_mask, T32, num_iters, lr, lr_end_factor, wan
     return losses[:num_iters] if want_losses else None
 
 
-def fit_flags(cholesky_qr=False, library_eigh=False, exact_final=False, sketch_split=True):
-    return int(bool(cholesky_qr)) | (4 if library_eigh else 0) | (8 if exact_final else 0) | (0 if sketch_split else 16)
+def fit_flags(cholesky_qr=False, library_eigh=False, sketch_split=True):
+    return int(bool(cholesky_qr)) | (4 if library_eigh else 0) | (0 if sketch_split else 16)
 
 
 def fit_subspace(N, K, r, oversample):

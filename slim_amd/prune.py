@@ -405,6 +405,208 @@ def compress_linears(items, dev, *args, level_hints=None, **kwargs):
             level_hints[keys[i]] = _lora.level_hint_from_status(*word)
 
 
+class _MemberPhases:
+    """The per-linear phases of one compress_linears call, bound to its recipe: mask -> first quantisation and error matrix
+    (prepare, optionally with the split-off of the outlier columns) ... the fit, run by the caller ... residual weight, second
+    quantisation, adapter attributes and hook (finish); or, without adapters, mask and quantisation (plain).  contexts[i] is
+    the LoraContext of items[i] between its prepare and its finish."""
+
+    def __init__(self, items, dev, prune_n, prune_m, sparsity_ratio, quantizer, lora_rank, slim_lora, prune_lora, tile, separate_lora,
+                 quantize_first, scale_important_weights, tiled_weight_quantization, callback, describe):
+        self.items, self.dev, self.prune_n, self.prune_m, self.sparsity_ratio = items, dev, prune_n, prune_m, sparsity_ratio
+        self.quantizer, self.lora_rank, self.slim_lora, self.prune_lora, self.tile = quantizer, lora_rank, slim_lora, prune_lora, tile
+        self.separate_lora, self.quantize_first, self.scale_important_weights = separate_lora, quantize_first, scale_important_weights
+        self.tiled_weight_quantization, self.callback, self.describe = tiled_weight_quantization, callback, describe
+        self.contexts = [None] * len(items)
+
+    def given_mask(self, lin):
+        """A precomputed (MaskLLM-style) mask attached to the weight, prune.py:269-271 (taken off the weight), or None."""
+        if not hasattr(lin.weight, "mask"):
+            return None
+        W_mask = lin.weight.mask.to(self.dev)
+        del lin.weight.mask
+        return W_mask
+
+    def mask_of(self, lin, wrapped):
+        W_mask = self.given_mask(lin)
+        if W_mask is not None:
+            return W_mask
+        if self.prune_n != 0:
+            return ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), self.prune_n, self.prune_m)
+        # unstructured (prune.py:275-279): per row the int(K * ratio) smallest saliencies, ties to the lower index
+        K = lin.weight.shape[1]
+        return ops.mask_unstructured(lin.weight.data.contiguous(), ops.sqrt(wrapped.scaler_row), int(K * self.sparsity_ratio))
+
+    @staticmethod
+    def produced(lin):
+        """The tensors a job leaves on its linear (run_on_streams hands them back to the caller's stream)."""
+        return [lin.weight.data, getattr(lin, "scaling_factor", None)] + \
+               [p.data for p in (getattr(lin, "lora_left", None), getattr(lin, "lora_right", None)) if p is not None]
+
+    def plain(self, idx):
+        """No adapters (prune.py:330-357): quantise the dense weight then zero the mask, or the other way round."""
+        name, lin, wrapped = self.items[idx]
+        quantizer = self.quantizer
+        if self.describe:
+            self.describe(name)
+        W_mask = self.mask_of(lin, wrapped)
+        important = None
+        if self.scale_important_weights:
+            # prune.py:331-335 reads `scaler_row` off the nn.Linear, which has none: the reference raises here
+            important = ops.important_columns(lin.weight.data, lin.scaler_row)
+
+        def quantise():
+            if quantizer is not None:
+                codes = quantizer.quantize_weight(lin.weight.data, important)
+                lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
+                lin.scaling_factor = None if self.tiled_weight_quantization else quantizer.scaling_factor
+        if self.quantize_first:
+            quantise()
+            lin.weight.data[W_mask] = 0
+        else:
+            lin.weight.data[W_mask] = 0
+            quantise()
+        if self.callback is not None:
+            self.callback(name, lin, wrapped)
+        return self.produced(lin)
+
+    def prepare(self, idx):
+        from .lora import add_lora_prepare
+        name, lin, wrapped = self.items[idx]
+        if self.describe:
+            self.describe(name)
+        self.contexts[idx] = add_lora_prepare(lin, self.mask_of(lin, wrapped), self.lora_rank, self.slim_lora, wrapped, self.quantizer,
+                                              self.prune_lora, self.separate_lora, self.tile, self.quantize_first,
+                                              self.scale_important_weights)
+        return self.contexts[idx].tensors()
+
+    def prepare_and_deflate(self, idx):
+        """prepare plus the split-off of the outlier columns; as ONE library call where the recipe allows."""
+        from . import lora as _lora
+        name, lin, wrapped = self.items[idx]
+        if FUSED_PREPARE and _lora.prepare_fusable(lin, self.quantizer, self.slim_lora, self.prune_lora, self.separate_lora,
+                                                   self.quantize_first, self.scale_important_weights, self.prune_n):
+            if self.describe:
+                self.describe(name)
+            self.contexts[idx] = _lora.add_lora_prepare_fused(lin, self.prune_n, self.prune_m, self.lora_rank, self.slim_lora, wrapped,
+                                                              self.quantizer, self.tile, self.given_mask(lin))
+        else:
+            self.prepare(idx)
+            _lora.add_lora_deflate(self.contexts[idx])
+        return self.contexts[idx].tensors()
+
+    def finish(self, idx):
+        from .lora import add_lora_finish
+        name, lin, wrapped = self.items[idx]
+        sf = add_lora_finish(self.contexts[idx], prescale=self.separate_lora)     # prune.py:296-301: adapters stored times sqrt(rank)
+        if self.quantizer is not None:
+            lin.scaling_factor = None if self.tiled_weight_quantization else sf
+        if self.separate_lora:
+            lin.register_forward_hook(add_lora_hook)
+        if self.callback is not None:
+            self.callback(name, lin, wrapped)
+        self.contexts[idx] = None
+        return self.produced(lin)
+
+
+def _run_fit_chains(phases, plans, n_streams):
+    """The adapters of a block through lockstep chains around a shared Rayleigh-Ritz stage.
+
+    The fits of a block pose one l x l eigenproblem each, whose solver is a chain of dependent launches: seven chains side by
+    side take seven times the launches on four in-order hardware queues.  So linears with equal plans (plans[i] = (key, l)
+    from lora.planned_fit_group: same short dimension, rank, Newton-Schulz depth and filter class -- the shapes may differ)
+    run as ONE chain whose subspace iteration is a single batched launch sequence; GROUP_MAX caps the members of a chain,
+    and several chains overlap on streams of their own."""
+    from . import lora as _lora
+    items, dev, ctxs = phases.items, phases.dev, phases.contexts
+    fit_groups, seen = {}, {}
+    for idx, (key, l) in enumerate(plans):
+        n_seen = seen.get((key, l), 0)
+        seen[(key, l)] = n_seen + 1
+        part = n_seen // GROUP_MAX if GROUP_MAX > 0 else 0          # at most GROUP_MAX members per chain
+        fit_groups.setdefault((key, l, part) if GROUP_FITS else (key, l, idx), []).append(idx)
+    fit_groups = list(fit_groups.items())
+    count, where = {}, []
+    for gkey, members in fit_groups:
+        l = gkey[1]
+        where.append((l, count.get(l, 0)))
+        count[l] = count.get(l, 0) + len(members)
+    Mb = {l: torch.empty(n, l, l, dtype=torch.float32, device=dev) for l, n in count.items()}
+    split = len(items) < 3          # fewer fits than that do not fill the chip by themselves
+
+    def fit_front(g):
+        members = fit_groups[g][1]
+        l, b0 = where[g]
+        if len(members) == 1:
+            _lora.add_lora_fit_front(ctxs[members[0]], Mb[l][b0], sketch_split=split)
+        else:
+            _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], sketch_split=split)
+
+    def fit_back(g, evals, vecs, tail):
+        members = fit_groups[g][1]
+        if len(members) == 1:
+            _lora.add_lora_fit_back(ctxs[members[0]], evals[0], None, None, vecs[0], tail[0:1])
+        else:
+            _lora.add_lora_fit_back_group([ctxs[i] for i in members], evals, None, None, vecs, tail)
+
+    def fit_rank(g):
+        return ctxs[fit_groups[g][1][0]].pending["ctx"]["r"]
+
+    ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
+    if PIPELINE_GROUPS and len(fit_groups) <= 4:
+        # every chain runs whole -- its members' first phases, the lockstep front, its own Rayleigh-Ritz stage, the factors, its
+        # members' last phases -- on its stream without waiting for the others: the latency-bound launches of one chain
+        # overlap the GEMMs of the others.  (More host threads than chains do not pay: spreading the members' first phases
+        # over seven threads was slower than running them in the chain.)
+        def whole_chain(g):
+            members = fit_groups[g][1]
+            l, b0 = where[g]
+            mark = _phase_marker(g)
+            for i in members:
+                phases.prepare_and_deflate(i)
+            mark("prepare")
+            fit_front(g)
+            mark("front")
+            Mg = Mb[l][b0:b0 + len(members)]
+            evals, vecs, tail = _lora.rayleigh_ritz(Mg, fit_rank(g), [_lora.fit_keep(ctxs[i]) for i in members],
+                                                    max(ctxs[i].cond_floor for i in members))
+            mark("rayleigh_ritz")
+            fit_back(g, evals, vecs, tail)
+            mark("back")
+            out = [evals, vecs, tail]
+            for i in members:
+                out += phases.finish(i)
+            mark("finish")
+            return out
+        run_on_streams([lambda g=g: whole_chain(g) for g in range(len(fit_groups))], dev, n_streams, ids)
+        return
+
+    # more chains than streams to pipeline them on: phase by phase, the eigenproblems of the block size by size in between
+    def front(g):
+        for i in fit_groups[g][1]:
+            phases.prepare(i)
+        fit_front(g)
+        return [x for i in fit_groups[g][1] for x in ctxs[i].tensors()]
+    run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
+    top, keeps = {}, {}
+    for g in range(len(fit_groups)):
+        l = where[g][0]
+        top[l] = max(top.get(l, 0), fit_rank(g))
+        keeps.setdefault(l, []).extend(_lora.fit_keep(ctxs[i]) for i in fit_groups[g][1])
+    floor = max(c.cond_floor for c in ctxs)
+    rr = {l: _lora.rayleigh_ritz(Mb[l], top[l], keeps[l], floor) for l in sorted(Mb)}
+
+    def back(g):
+        members = fit_groups[g][1]
+        l, b0 = where[g]
+        sl = slice(b0, b0 + len(members))
+        evals, vecs, tails = rr[l]
+        fit_back(g, evals[sl], vecs[sl], tails[sl])
+        return [x for i in members for x in ctxs[i].tensors()]
+    run_on_streams([lambda g=g: back(g) for g in range(len(fit_groups))], dev, n_streams, ids)
+    run_on_streams([lambda i=i: phases.finish(i) for i in range(len(items))], dev, n_streams)
+
+
 def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5, quantizer=None, lora_rank=0., slim_lora=True, prune_lora=False,
                      quantize_lora=False, pad_lora=False, lora_tile_size=256, separate_lora=True, quantize_first=True,
                      scale_important_weights=False, tiled_weight_quantization=False, callback=None, describe=None,
@@ -412,215 +614,38 @@ def compress_linears_unchecked(items, dev, prune_n, prune_m, sparsity_ratio=0.5,
     """Compress the linears of one block after their statistics pass (the body of the per-linear loop of
     prune.py:256-357).  items: list of (name, nn.Linear, WrappedGPT) with block_stats() already applied.
 
-    With adapters the linears whose fits have the same short dimension, rank and Newton-Schulz depth form chains of at most
-    GROUP_MAX members, every chain on a side stream of its own: per member mask, first scale search, error matrix, outlier
-    columns split off; the low-rank fit of all members in lockstep up to their l x l Rayleigh-Ritz matrices (the subspace
-    iteration as one batched launch sequence); one batched eigen-solver chain; the factors; per member residual weight,
-    second scale search, re-quantisation, adapter attributes and hook.
+    Three ways through, by recipe: no adapters -- mask and quantisation per linear (_MemberPhases.plain); separate, unpruned
+    adapters on more than one linear -- lockstep chains (_run_fit_chains); otherwise -- the three phases of every linear back
+    to back on a stream of its own.
     shard=True (several ranks, every rank passing the same items): the row-block partition of sharded.py instead."""
-    from .lora import add_lora_prepare, add_lora_fit, add_lora_finish, add_lora_deflate
+    tile = lora_tile_size if (quantize_lora or pad_lora) else None
     if shard:
         # every rank holds a block of every linear (the caller has checked sharded.supported on these items)
         from . import sharded
-        sharded.compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank, slim_lora,
-                                         lora_tile_size if (quantize_lora or pad_lora) else None, callback, describe)
+        sharded.compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank, slim_lora, tile, callback, describe)
         return
-
-    def mask_of(lin, wrapped):
-        if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
-            W_mask = lin.weight.mask.to(dev)
-            del lin.weight.mask
-            return W_mask
-        if prune_n != 0:
-            return ops.mask_nm(lin.weight.data, ops.sqrt(wrapped.scaler_row), prune_n, prune_m)
-        # unstructured (prune.py:275-279): per row the int(K * ratio) smallest saliencies, ties to the lower index
-        K = lin.weight.shape[1]
-        return ops.mask_unstructured(lin.weight.data.contiguous(), ops.sqrt(wrapped.scaler_row), int(K * sparsity_ratio))
-
-    def produced(lin):
-        return [lin.weight.data, getattr(lin, "scaling_factor", None)] + \
-               [p.data for p in (getattr(lin, "lora_left", None), getattr(lin, "lora_right", None)) if p is not None]
-
+    phases = _MemberPhases(items, dev, prune_n, prune_m, sparsity_ratio, quantizer, lora_rank, slim_lora, prune_lora, tile, separate_lora,
+                           quantize_first, scale_important_weights, tiled_weight_quantization, callback, describe)
     if not lora_rank > 0.:
-        def plain(name, lin, wrapped):
-            if describe:
-                describe(name)
-            W_mask = mask_of(lin, wrapped)
-            important = None
-            if scale_important_weights:
-                # prune.py:331-335 reads `scaler_row` off the nn.Linear, which has none: the reference raises here
-                important = ops.important_columns(lin.weight.data, lin.scaler_row)
-            # prune.py:330-357: quantise the dense weight then zero the mask, or the other way round
-            def quantise():
-                if quantizer is not None:
-                    codes = quantizer.quantize_weight(lin.weight.data, important)
-                    lin.weight.data = quantizer.dequantize_absmax(codes).to(torch.bfloat16)
-                    lin.scaling_factor = None if tiled_weight_quantization else quantizer.scaling_factor
-            if quantize_first:
-                quantise()
-                lin.weight.data[W_mask] = 0
-            else:
-                lin.weight.data[W_mask] = 0
-                quantise()
-            if callback is not None:
-                callback(name, lin, wrapped)
-            return produced(lin)
         # the shared quantizer keeps its last scale as state, so these jobs stay on one thread
-        run_on_streams([lambda it=it: plain(*it) for it in items], dev, 1)
+        run_on_streams([lambda i=i: phases.plain(i) for i in range(len(items))], dev, 1)
         return
-
-    tile = lora_tile_size if (quantize_lora or pad_lora) else None
     for _, _, wrapped in items:
         if getattr(wrapped, "has_zero", None) is None:
             block_stats([wrapped])
-    ctxs = [None] * len(items)
-
-    def prepare(idx):
-        name, lin, wrapped = items[idx]
-        if describe:
-            describe(name)
-        ctxs[idx] = add_lora_prepare(lin, mask_of(lin, wrapped), lora_rank, slim_lora, wrapped, quantizer, prune_lora,
-                                     separate_lora, tile, quantize_first, scale_important_weights)
-        return ctxs[idx].tensors()
-
-    def finish(idx):
-        name, lin, wrapped = items[idx]
-        sf = add_lora_finish(ctxs[idx], prescale=separate_lora)       # prune.py:296-301: adapters stored times sqrt(rank)
-        if quantizer is not None:
-            lin.scaling_factor = None if tiled_weight_quantization else sf
-        if separate_lora:
-            lin.register_forward_hook(add_lora_hook)
-        if callback is not None:
-            callback(name, lin, wrapped)
-        ctxs[idx] = None
-        return produced(lin)
-
     if SHARED_EIGH and separate_lora and not prune_lora and len(items) > 1:
-        # The fits of a block pose one l x l eigenproblem each, and its first stage (Householder tridiagonalisation) is a
-        # chain of l dependent launches: seven chains side by side take seven times the launches on four in-order
-        # hardware queues.  So the linears run to their Rayleigh-Ritz matrix on the side streams, ONE batched chain
-        # tridiagonalises all matrices of equal size, and the linears finish on the side streams again.
         from . import lora as _lora
         plans = [_lora.planned_fit_group(lin, lora_rank, tile, slim_lora, wrapped) for _, lin, wrapped in items]
         if all(p is not None for p in plans):
-            # linears with equal plans (all seven of a LLaMA block: same short dimension, rank and Newton-Schulz depth) run
-            # as ONE lockstep chain whose subspace iteration is a single batched launch sequence; SLIM_GROUP_MAX caps the
-            # members of a chain, and several chains overlap on their own streams
-            fit_groups = {}
-            seen = {}
-            for idx, (key, l) in enumerate(plans):
-                n_seen = seen.get((key, l), 0)
-                seen[(key, l)] = n_seen + 1
-                part = n_seen // GROUP_MAX if GROUP_MAX > 0 else 0          # at most GROUP_MAX members per chain
-                fit_groups.setdefault((key, l, part) if GROUP_FITS else (key, l, idx), []).append(idx)
-            fit_groups = list(fit_groups.items())
-            count, where = {}, []
-            for gkey, members in fit_groups:
-                l = gkey[1]
-                where.append((l, count.get(l, 0)))
-                count[l] = count.get(l, 0) + len(members)
-            Mb = {l: torch.empty(n, l, l, dtype=torch.float32, device=dev) for l, n in count.items()}
-            split = len(items) < 3          # fewer fits than that do not fill the chip by themselves
-
-            def fit_front(g):
-                members = fit_groups[g][1]
-                l, b0 = where[g]
-                if len(members) == 1:
-                    _lora.add_lora_fit_front(ctxs[members[0]], Mb[l][b0], sketch_split=split)
-                else:
-                    _lora.add_lora_fit_front_group([ctxs[i] for i in members], Mb[l][b0:b0 + len(members)], sketch_split=split)
-
-            def fit_back(g, d, e, Q, Mg, tail):
-                members = fit_groups[g][1]
-                if len(members) == 1:
-                    _lora.add_lora_fit_back(ctxs[members[0]], d[0], None if e is None else e[0], None if Q is None else Q[0], Mg[0],
-                                            tail[0:1])
-                else:
-                    _lora.add_lora_fit_back_group([ctxs[i] for i in members], d, e, Q, Mg, tail)
-
-            def fit_rank(g):
-                ctx = ctxs[fit_groups[g][1][0]].pending["ctx"]
-                return ctx["r"]
-
-            ids = GROUP_STREAM_IDS if len(fit_groups) <= len(GROUP_STREAM_IDS) else None
-            def prepare_and_deflate(idx):
-                name, lin, wrapped = items[idx]
-                if FUSED_PREPARE and _lora.prepare_fusable(lin, quantizer, slim_lora, prune_lora, separate_lora, quantize_first,
-                                                           scale_important_weights, prune_n):
-                    # mask, first scale search, error matrix and the split-off of the outlier columns as one library call
-                    if describe:
-                        describe(name)
-                    given = None
-                    if hasattr(lin.weight, "mask"):              # precomputed (MaskLLM-style) mask, prune.py:269-271
-                        given = lin.weight.mask.to(dev)
-                        del lin.weight.mask
-                    ctxs[idx] = _lora.add_lora_prepare_fused(lin, prune_n, prune_m, lora_rank, slim_lora, wrapped, quantizer, tile,
-                                                             given)
-                else:
-                    prepare(idx)
-                    add_lora_deflate(ctxs[idx])
-                return ctxs[idx].tensors()
-
-            if PIPELINE_GROUPS and len(fit_groups) <= 4:
-                # every chain runs whole -- its members' first phases, the lockstep front, its own batched eigen-solver chain, the
-                # factors, its members' last phases -- on its stream without waiting for the others: the latency-bound
-                # eigen-solver launches of a chain overlap the GEMMs of the others.  (More host threads than chains do not
-                # pay: spreading the members' first phases over seven threads was slower than running them in the chain.)
-                def whole_group(g):
-                    members = fit_groups[g][1]
-                    l, b0 = where[g]
-                    mark = _phase_marker(g)
-                    for i in members:
-                        prepare_and_deflate(i)
-                    mark("prepare")
-                    fit_front(g)
-                    mark("front")
-                    Mg = Mb[l][b0:b0 + len(members)]
-                    evals, vecs, tail = _lora.rayleigh_ritz(Mg, fit_rank(g), [_lora.fit_keep(ctxs[i]) for i in members],
-                                                            max(ctxs[i].cond_floor for i in members))
-                    mark("rayleigh_ritz")
-                    fit_back(g, evals, None, None, vecs, tail)
-                    mark("back")
-                    out = [evals, vecs, tail]
-                    for i in members:
-                        out += finish(i)
-                    mark("finish")
-                    return out
-                run_on_streams([lambda g=g: whole_group(g) for g in range(len(fit_groups))], dev, n_streams, ids)
-                return
-
-            def front(g):
-                for i in fit_groups[g][1]:
-                    prepare(i)
-                fit_front(g)
-                return [x for i in fit_groups[g][1] for x in ctxs[i].tensors()]
-            run_on_streams([lambda g=g: front(g) for g in range(len(fit_groups))], dev, n_streams, ids)
-            # the eigenproblems of the block, size by size: one tridiagonalisation chain and three launches for the
-            # tridiagonal stage, each carrying every problem of that size
-            top, keeps = {}, {}
-            for g in range(len(fit_groups)):
-                l = where[g][0]
-                top[l] = max(top.get(l, 0), fit_rank(g))
-                keeps.setdefault(l, []).extend(_lora.fit_keep(ctxs[i]) for i in fit_groups[g][1])
-            floor = max(c.cond_floor for c in ctxs)
-            rr = {l: _lora.rayleigh_ritz(Mb[l], top[l], keeps[l], floor) for l in sorted(Mb)}
-
-            def back(g):
-                members = fit_groups[g][1]
-                l, b0 = where[g]
-                sl = slice(b0, b0 + len(members))
-                evals, vecs, tails = rr[l]
-                fit_back(g, evals[sl], None, None, vecs[sl], tails[sl])
-                return [x for i in members for x in ctxs[i].tensors()]
-            run_on_streams([lambda g=g: back(g) for g in range(len(fit_groups))], dev, n_streams, ids)
-            run_on_streams([lambda i=i: finish(i) for i in range(len(items))], dev, n_streams)
+            _run_fit_chains(phases, plans, n_streams)
             return
-    # a single linear, pruned or merged adapters, or an eigenproblem the shared solver does not take: the three phases of a
-    # linear run back to back on one stream, and the linears overlap freely
+    # a single linear, pruned or merged adapters, or an eigenproblem the shared stage does not take
+    from .lora import add_lora_fit
+
     def whole(idx):
-        prepare(idx)
-        add_lora_fit([ctxs[idx]])
-        return finish(idx)
+        phases.prepare(idx)
+        add_lora_fit([phases.contexts[idx]])
+        return phases.finish(idx)
     run_on_streams([lambda i=i: whole(i) for i in range(len(items))], dev, n_streams)
 
 

@@ -11,7 +11,7 @@ mask = ops.mask_nm(W, s, 2, 4); sf = ops.quant_search(ops.hist_abs(W), max(512, 
 _, E = ops.error_matrix(W, mask, s, sf, 4); Et = ops.transpose(E); Ef = E.float()
 sv = torch.linalg.svdvals(Ef); opt = float(torch.sqrt((sv[r:] ** 2).sum()))
 print(f"{N}x{K} r={r}: s1/sr {float(sv[0]/sv[r-1]):.1f}")
-for kw in (dict(cholesky_qr=True), dict(ns_steps=4), dict(ns_steps=4, exact_final=True), dict(ns_steps=12), dict(ns_steps=12, exact_final=True)):
+for kw in (dict(cholesky_qr=True), dict(ns_steps=4), dict(ns_steps=12)):
     f = ops.lowrank_fit(E, Et, r, r // 4, 10, seed=0, **kw)
     U, L = f["U"].float(), f["L"].float()
     err = float(torch.norm(Ef - U @ L.t())) / opt - 1
