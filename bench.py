@@ -317,7 +317,7 @@ def main():
             wrapped[i].scaler_row = ops.shift_zeros(wrapped[i].scaler_row)
         block_stats(list(wrapped.values()))
         compress_linears([(LLAMA2_7B_BLOCK[i][0], lins[i], wrapped[i]) for i in wrapped], dev, 2, 4,
-                         quantizer=Quantizer("weight", num_bits=4, slim_quant=True), shard=True, **recipe)
+                         quantizer=Quantizer("weight", num_bits=4, slim_quant=True), shard=True, level_hints=level_hints, **recipe)
         for i in wrapped:                   # the storage form of every linear is made once, round-robin over the ranks
             if i % world == rank:
                 packed[i] = ops.pack24(lins[i].weight.data, lins[i].scaling_factor, check=False)

@@ -379,6 +379,19 @@ int slim_lowrank_fit_back_group(const int64_t* Ns, const int64_t* Ks, int batch,
 int64_t slim_gramfit_workspace_bytes(int64_t rows, int64_t l);
 int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_iter, uint32_t seed, int flags, int cond_e, void* P, void* Pt,
                          int32_t* info_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* slim_gramfit_iterate for `batch` Gram matrices of one size in lockstep (C16 [batch][Dm, Dm], P [batch][Dm, l], Pt [batch][l, Dm],
+ * info_out [batch][SLIM_FIT_INFO_WORDS]).  Honours a request left by slim_lowrank_fit_set_filter on the calling thread (one
+ * ratio per matrix): the filtered iteration shifts the diagonals of C16 in place.  scal_out (optional, [batch][4] floats) is
+ * what slim_gramfit_check takes.  No counterpart in the reference (single-GPU, full SVD: slim/lora.py:172). */
+int64_t slim_gramfit_batched_workspace_bytes(int batch, int64_t rows, int64_t l);
+int slim_gramfit_iterate_batched(void* C16, int batch, int64_t Dm, int l, int n_iter, uint32_t seed, int flags, int cond_e, void* P,
+                                 void* Pt, int32_t* info_out, float* scal_out, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
+/* The three report words of a finished fit (SLIM_FIT_INFO_COND_WORD / _LEVEL_WORD / _RATIO_WORD of info
+ * [batch][SLIM_FIT_INFO_WORDS]) from the eigenvalues of the Rayleigh-Ritz matrices (evals [batch][l], ascending); scal: the
+ * scal_out of slim_gramfit_iterate_batched, or NULL. */
+int slim_gramfit_check(const float* evals, int l, int r, int batch, int cond_e, const float* scal, int32_t* info, void* stream);
+
 int slim_gramfit_project(const void* X, int64_t rows, int64_t Dm, int l, const void* Pt, void* Z, void* Zt, float* M32,
                          void* workspace, int64_t workspace_bytes, void* stream);
 int slim_gramfit_factors(int right, const void* P, const void* Z, int64_t Dm, int64_t rows, int l, int r, const float* vecs,

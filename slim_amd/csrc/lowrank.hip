@@ -1540,6 +1540,58 @@ extern "C" int slim_gramfit_iterate(const void* C16, int64_t Dm, int l, int n_it
     return SLIM_OK;
 }
 
+// slim_gramfit_iterate for `batch` Gram matrices of one size in lockstep (C16 [batch][Dm, Dm]; P [batch][Dm, l], Pt [batch][l, Dm],
+// info_out [batch][SLIM_FIT_INFO_WORDS]): every launch carries the whole batch, as in slim_lowrank_fit_front_batched.  A
+// request left by slim_lowrank_fit_set_filter on the calling thread (one ratio per matrix) is honoured: the Chebyshev-
+// filtered iteration, which shifts the diagonals of C16 IN PLACE.  scal_out (optional, [batch][4] floats): per matrix
+// {-, mean eigenvalue trace / Dm, upper end beta of the damped interval or 0, -} for slim_gramfit_check.
+extern "C" int64_t slim_gramfit_batched_workspace_bytes(int batch, int64_t rows, int64_t l) {
+    if (batch <= 0 || rows <= 0 || l <= 0) return 0;
+    return fit_ws(nullptr, batch, rows, 8, l).total;
+}
+
+extern "C" int slim_gramfit_iterate_batched(void* C16, int batch, int64_t Dm, int l, int n_iter, uint32_t seed, int flags, int cond_e,
+                                            void* P, void* Pt, int32_t* info_out, float* scal_out, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
+    SLIM_REQUIRE(C16 && P && Pt && workspace, "slim_gramfit_iterate_batched: null pointer");
+    SLIM_REQUIRE(batch >= 1 && batch <= FILTER_MAX && Dm > 0 && l > 0 && l < Dm && Dm % 8 == 0 && l % 8 == 0 && n_iter >= 0,
+                 "slim_gramfit_iterate_batched: bad sizes");
+    SLIM_REQUIRE(2 * (n_iter + 1) + 1 <= SLIM_FIT_INFO_WORDS / 2, "slim_gramfit_iterate_batched: too many iterations");
+    SLIM_REQUIRE(workspace_bytes >= slim_gramfit_batched_workspace_bytes(batch, Dm, l), "slim_gramfit_iterate_batched: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    FitWs w = fit_ws((char*)workspace, batch, Dm, 8, l);
+    SLIM_HIP(hipMemsetAsync(w.info, 0, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), st));
+    SLIM_HIP(hipMemsetAsync(w.scal, 0, (size_t)batch * SCAL_STRIDE * sizeof(float), st));
+    const int cond = ns_levels_clamped(cond_e);
+    float fr[FILTER_MAX];
+    int fbits = 0, a = 0, ninfo = 0;
+    const bool filt = take_filter(batch, fr, &fbits);
+    // several problems side by side fill the chip: no split of the products along their reduction
+    const bool alone = batch == 1 && !(flags & SLIM_FIT_NO_SKETCH_SPLIT);
+    if (!alone) w.gram_cap = GRAM_SPLITS_SHARED_CHIP;
+    CHK(gram_iterate(w.A, (bf16_t*)C16, Dm * Dm, batch, Dm, l, n_iter, seed, flags & ~SLIM_FIT_CHOLESKY_QR, cond, w,
+                     alone ? w.sketch_slab : nullptr, (int64_t)SKETCH_MAX_SPLITS * l * Dm, stream, &a, &ninfo, filt ? fr : nullptr, fbits));
+    const size_t bytes = (size_t)batch * Dm * l * sizeof(bf16_t);
+    SLIM_HIP(hipMemcpyAsync(P, w.A[a].X, bytes, hipMemcpyDeviceToDevice, st));
+    SLIM_HIP(hipMemcpyAsync(Pt, w.A[a].Xt, bytes, hipMemcpyDeviceToDevice, st));
+    if (info_out)
+        SLIM_HIP(hipMemcpyAsync(info_out, w.info, (size_t)batch * SLIM_FIT_INFO_WORDS * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (scal_out)
+        SLIM_HIP(hipMemcpyAsync(scal_out, w.scal, (size_t)batch * SCAL_STRIDE * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return SLIM_OK;
+}
+
+// The reports of a finished fit for `batch` problems (words SLIM_FIT_INFO_COND_WORD, _LEVEL_WORD, _RATIO_WORD of info
+// [batch][SLIM_FIT_INFO_WORDS]) from the eigenvalues of their Rayleigh-Ritz matrices (evals [batch][l] ascending, or a
+// Ritz split's estimates in that layout), for an iteration sized for cond_e; scal (optional): what
+// slim_gramfit_iterate_batched left in scal_out, for the ratio word and the check of the filter's interval.
+extern "C" int slim_gramfit_check(const float* evals, int l, int r, int batch, int cond_e, const float* scal, int32_t* info, void* stream) {
+    SLIM_REQUIRE(evals && info && l > 0 && r > 0 && r <= l && batch >= 1, "slim_gramfit_check: bad arguments");
+    cond_check_kernel<<<(batch + 63) / 64, 64, 0, (hipStream_t)stream>>>(evals, l, r, batch, ns_levels_clamped(cond_e), info, scal);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 // Z [rows, l] = X P and Z^T, M32 [l, l] = Z^T Z (fp32): X [rows, Dm] is the shard of E (or of E^T) whose columns the basis P
 // [Dm, l] (given as Pt [l, Dm]) spans
 extern "C" int slim_gramfit_project(const void* X, int64_t rows, int64_t Dm, int l, const void* Pt, void* Z, void* Zt, float* M32,

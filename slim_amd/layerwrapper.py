@@ -43,7 +43,7 @@ class WrappedGPT:
     reference) is kept when `track_inp_sum=True`.
     """
 
-    def __init__(self, layer, layer_id=0, layer_name="none", track_inp_sum=False, defer=False):
+    def __init__(self, layer, layer_id=0, layer_name="none", track_inp_sum=False, defer=False, collect_gram=False):
         self.layer = layer
         self.dev = self.layer.weight.device
         self.rows = layer.weight.data.shape[0]
@@ -59,6 +59,13 @@ class WrappedGPT:
         # shards the samples over several GPUs gathers them into sample order first (finish_deferred)
         self.defer = defer
         self.sample_sums = []
+        # collect_gram=True: also the Gram statistic of the reference's SparseGPT wrapper (sparsegpt.py:26, :28-39),
+        # H = (2 / n) sum_samples X^T X in fp32 [K, K], the only place the reference forms a Gram matrix of the calibration
+        # inputs; diag(H) / 2 equals scaler_row.  Each rank of a run that shards the calibration samples (tokens) holds the
+        # H of its share until reduce_gram combines them.
+        self.collect_gram = bool(collect_gram)
+        self.H = torch.zeros((self.columns, self.columns), device=self.dev) if collect_gram else None
+        self.gram_nsamples = 0
 
     def add_batch(self, inp, out=None, per_sample=False):
         """One forward call's input `inp` ([B, S, K] or [S, K], bf16).
@@ -80,6 +87,12 @@ class WrappedGPT:
         self.inp_num += b if per_sample else 1
         if flat.dtype != torch.bfloat16:
             raise TypeError("WrappedGPT.add_batch expects bf16 activations")
+        if self.collect_gram:
+            # sparsegpt.py:36-39 with batch = b: H <- H n / (n + b) + (2 / (n + b)) X^T X.  The recurrence keeps
+            # H = (2 / n) sum X^T X whatever the batching, so b single-sample updates give the same matrix up to the order of
+            # fp32 additions (1e-6 relative); one update per call is taken for both settings of per_sample.
+            ops.gram_accum(flat, self.H, self.gram_nsamples, b)
+            self.gram_nsamples += b
         if self.defer:
             if not per_sample:
                 raise ValueError("deferred statistics are kept per sample")
@@ -93,6 +106,26 @@ class WrappedGPT:
         else:
             ops.scaler_row_accum(flat, self.scaler_row, self.nsamples, n_chunks=1, batch_per_chunk=b)
         self.nsamples += b
+
+    def reduce_gram(self, all_reduce=None):
+        """Token-sharded calibration: every rank has folded ITS samples into H = (2 / n_rank) sum X^T X.  The matrix over all
+        samples is the mean of the ranks' matrices weighted by their sample counts, H = sum_ranks (n_rank / n) H_rank with
+        n = sum n_rank: one all-reduce(SUM) of the pre-weighted matrices (and one of the counts).  all_reduce: in-place sum
+        over the ranks (parallel.all_reduce); None: a single rank, nothing to do.  Afterwards H and gram_nsamples are the
+        same on every rank and equal to a single-rank pass over all samples up to fp32 summation order."""
+        if not self.collect_gram:
+            raise ValueError("this wrapper does not collect the Gram matrix (collect_gram=True)")
+        if all_reduce is None:
+            return self.H
+        count = torch.tensor([float(self.gram_nsamples)], dtype=torch.float64, device=self.H.device)
+        local = float(count.item())
+        all_reduce(count)
+        total = float(count.item())
+        if total > 0:
+            self.H *= local / total
+        all_reduce(self.H)
+        self.gram_nsamples = int(total)
+        return self.H
 
     def finish_deferred(self, gather=None):
         """Fold the kept per-sample sums (after `gather`, e.g. parallel.gather_sample_stats, has put the sums

@@ -290,8 +290,9 @@ def transpose(x, out=None):
     return out
 
 
-def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False):
-    """C = alpha * A @ Bt.T (+ beta * C32). Returns (C fp32 | None, C bf16 | None, C^T bf16 | None)."""
+def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False, C16=None):
+    """C = alpha * A @ Bt.T (+ beta * C32). Returns (C fp32 | None, C bf16 | None, C^T bf16 | None).  C16 (optional): a
+    contiguous bf16 [M, N] tensor that receives the bf16 result (implies out_bf16)."""
     A = _chk(A, BF16, "A")
     Bt = _chk(Bt, BF16, "Bt")
     M, Kd = A.shape
@@ -300,7 +301,12 @@ def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False,
     dev = A.device
     if C32 is None and out_f32:
         C32 = torch.empty(M, N, dtype=torch.float32, device=dev)
-    C16 = torch.empty(M, N, dtype=BF16, device=dev) if out_bf16 else None
+    if C16 is not None:
+        _chk(C16, BF16, "C16")
+        if tuple(C16.shape) != (M, N) or not C16.is_contiguous():
+            raise ValueError("C16 must be a contiguous [M, N] tensor")
+    elif out_bf16:
+        C16 = torch.empty(M, N, dtype=BF16, device=dev)
     Ct = torch.empty(N, M, dtype=BF16, device=dev) if out_t else None
     _lib.call("slim_gemm_nt_bf16", _p(A), Kd, _p(Bt), Kd, M, N, Kd, float(alpha), float(beta), _p(C32), N, _p(C16), N,
               _p(Ct), M, _stream())
@@ -653,6 +659,36 @@ def gramfit_iterate(C16, l, n_iter, seed=0, flags=0, cond_e=0):
     _lib.call("slim_gramfit_iterate", _p(C16), Dm, int(l), int(n_iter), int(seed), int(flags), int(cond_e), _p(P), _p(Pt), _p(info),
               _p(ws), ws.numel(), _stream())
     return P, Pt, info
+
+
+def gramfit_iterate_batched(C16, l, n_iter, seed=0, flags=0, cond_e=0):
+    """gramfit_iterate for B same-size matrices in lockstep: C16 [B, Dm, Dm] -> (P [B, Dm, l], Pt [B, l, Dm], info int32
+    [B, 64], scal fp32 [B, 4] for gramfit_check).  A request left by set_fit_filter on this thread (B ratios) is honoured;
+    the filtered iteration shifts the diagonals of C16 in place."""
+    C16 = _chk(C16, BF16, "C16")
+    B, Dm, _ = C16.shape
+    dev = C16.device
+    P = torch.empty(B, Dm, l, dtype=BF16, device=dev)
+    Pt = torch.empty(B, l, Dm, dtype=BF16, device=dev)
+    info = torch.empty(B, 64, dtype=torch.int32, device=dev)
+    scal = torch.empty(B, 4, dtype=torch.float32, device=dev)
+    ws = _ws(_lib.query("slim_gramfit_batched_workspace_bytes", B, Dm, l), dev)
+    _lib.call("slim_gramfit_iterate_batched", _p(C16), B, Dm, int(l), int(n_iter), int(seed), int(flags), int(cond_e), _p(P), _p(Pt),
+              _p(info), _p(scal), _p(ws), ws.numel(), _stream())
+    return P, Pt, info, scal
+
+
+def gramfit_check(evals, r, cond_e, scal, info):
+    """The report words of finished fits (conditioning request, measured spread, where the cut sits: the last three of info
+    int32 [B, 64], written in place) from the eigenvalues evals [B, l] of their Rayleigh-Ritz matrices; scal: from
+    gramfit_iterate_batched, or None."""
+    evals = _chk(evals, torch.float32, "evals")
+    _chk(info, torch.int32, "info")
+    B, l = evals.shape
+    if info.numel() != B * 64 or (scal is not None and scal.numel() != B * 4):
+        raise ValueError("gramfit_check: info must hold 64 words and scal 4 floats per problem")
+    _lib.call("slim_gramfit_check", _p(evals), l, int(r), B, int(cond_e), _p(scal), _p(info), _stream())
+    return info
 
 
 def gramfit_project(X, Pt):

@@ -759,7 +759,7 @@ def prune_wanda(model, tokenizer, sparsity_ratio=0.5, prune_n=0, prune_m=0, quan
         if world > 1 and SHARD_LINEARS and not scale_important_weights and sharded.supported(everything, world, prune_n, prune_m, quantizer, lora_rank, slim_lora,
                                                              prune_lora, separate_lora, quantize_first, tile_rule):
             # every linear cut into blocks over all ranks; every rank ends with the whole compressed block
-            compress_linears(everything, dev, prune_n, prune_m, shard=True, **opts)
+            compress_linears(everything, dev, prune_n, prune_m, shard=True, level_hints=level_hints, **opts)
         else:
             owner = parallel.partition_by_cost([parallel.linear_cost(*subset[n].weight.shape) for n in names], world)
             compress_linears([it for j, it in enumerate(everything) if owner[j] == rank], dev, prune_n, prune_m,

@@ -18,10 +18,18 @@ Masks and first-pass codes are those of a single-GPU run bit for bit (same salie
 matrix is a sum of per-rank fp32 partial sums instead of one pass, so the factors agree with a single-GPU run to the
 accuracy of the fit (reconstruction error within 1e-3 of the truncated SVD's), not to the bit.
 """
+import os
+
 import torch
 
 from . import ops, parallel
 from . import lora as _lora
+
+# Side streams (each fed by a host thread) for the per-linear local phases.  Off by default: between the library calls these
+# phases are made of small torch operations (slices, copies, casts) whose host cost -- 30 to 45 us each here, under the
+# interpreter lock -- is what bounds the step, and threads only add contention there (measured on a LLaMA-2-7B-shaped block
+# on one rank: 20.5 ms in order, 27.6 ms over seven streams).
+SHARD_STREAMS = int(os.environ.get("SLIM_SHARD_STREAMS", "1"))
 
 ALIGN = 128      # shard boundaries: multiples of 128 (2:4 groups, 8-aligned MFMA reductions, 128-row packing tiles)
 
@@ -141,18 +149,54 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
                              describe=None, group=None):
     """The adapters branch of prune.compress_linears_unchecked for a block whose linears are all cut into blocks over the
     ranks (see the module docstring).  items: list of (name, nn.Linear, WrappedGPT) with prune.block_stats applied,
-    identical on every rank.  Leaves on every rank what the single-GPU path leaves: weight.data, lora_left, lora_right,
-    lora_rank, scaling_factor, the adapter hook, and lora_fit_info (int32 [64], maximised over the ranks: word 0 = a
-    status word of the fit was non-zero somewhere, last word = conditioning level the fit asks to be repeated with)."""
-    from .prune import add_lora_hook
+    identical on every rank (including the hints wrapped.fit_level_hint and the floors wrapped.fit_cond_floor that
+    prune.compress_linears sets).  Leaves on every rank what the single-GPU path leaves: weight.data, lora_left,
+    lora_right, lora_rank, scaling_factor, the adapter hook, and lora_fit_info (int32 [64], maximised over the ranks:
+    word 0 = a status word of the fit was non-zero somewhere, the last three = the fit's reports as slim_lowrank_fit leaves
+    them: conditioning level to repeat with, measured spread, where the cut sits).
+
+    The exchanges of a block are batched: ONE all-reduce carries the first-pass histograms of all linears, one the
+    second-pass histograms, one per eigenproblem size the Rayleigh-Ritz matrices, one the status words.  The owners run the
+    subspace iterations of their linears in lockstep (one batched launch sequence per class of equal size and depth,
+    Chebyshev-filtered when the hints carry the previous block's measurements, as on one GPU), and every rank solves the
+    small Rayleigh-Ritz stage of all linears itself, from identical input: no broadcast of eigenvectors."""
+    from .prune import add_lora_hook, run_on_streams
     rank, world = parallel.world_info(group)
-    jobs = []
-    # ---- phase 1: local elementwise stages, Gram contributions, iteration on the owners ---------------------------------
-    for idx, (name, lin, wrapped) in enumerate(items):
-        if describe:
-            describe(name)
-        j = _Job()
-        jobs.append(j)
+    n = len(items)
+    jobs = [_Job() for _ in items]
+    import time
+    trace = os.environ.get("SLIM_SHARD_TRACE") == "1"
+    t_host0 = time.perf_counter()
+    marks = []
+
+    def mark(name):
+        # (debugging aid: an event on the calling stream and the host clock per phase, printed at the end -- no waiting in between)
+        if trace:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev, (time.perf_counter() - t_host0) * 1e3))
+    mark("start")
+
+    def fan_out(fn, count=n):
+        """fn(i) for i < count on side streams (local work only: collectives stay on the calling thread, in one order on
+        every rank); the tensors the jobs hold are handed back to the calling stream."""
+        if torch.device(dev).type != "cuda" or SHARD_STREAMS <= 1:
+            for i in range(count):
+                fn(i)
+            return
+
+        def one(i):
+            fn(i)
+            return [t for j in jobs for t in vars(j).values() if isinstance(t, torch.Tensor)] if count != n else \
+                   [t for t in vars(jobs[i]).values() if isinstance(t, torch.Tensor)]
+        run_on_streams([lambda i=i: one(i) for i in range(count)], dev, SHARD_STREAMS)
+
+    # ---- phase 1a: masks and |W| histograms of the blocks; one all-reduce for the block's histograms ---------------------
+    hists = torch.zeros(n, 32768, dtype=torch.int32, device=dev)
+
+    def local_mask(idx):
+        name, lin, wrapped = items[idx]
+        j = jobs[idx]
         W = lin.weight.data
         N, K = W.shape
         j.N, j.K, j.right = N, K, K <= N
@@ -164,9 +208,14 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         use_slim = bool(slim_lora) and not wrapped.has_zero                        # lora.py:139
         s_mask = ops.sqrt(wrapped.scaler_row)                                       # prune.py:264-265
         j.s = s_mask if use_slim else None
-        outliers = wrapped.outliers if use_slim else None
-        j.rf, j.over, j.l, j.t = _lora.fit_plan(N, K, j.rank_, outliers)
-        j.cond = _lora.fit_ns_steps(wrapped.scale_spread if use_slim else 1.0)
+        j.outliers = wrapped.outliers if use_slim else None
+        j.rf, j.over, j.l, j.t = _lora.fit_plan(N, K, j.rank_, j.outliers)
+        # how the iteration is sized: as the single-GPU driver sizes it (hint of the previous block, floor of a repeat)
+        j.hint = int(getattr(wrapped, "fit_level_hint", 0) or 0)
+        j.floor = int(getattr(wrapped, "fit_cond_floor", 0) or 0)
+        j.plan = _lora.filter_plan([j.hint], j.floor)
+        j.cond = _lora.fit_ns_steps(wrapped.scale_spread if use_slim else 1.0, 0 if j.plan else j.hint, j.floor)
+        j.n_iter = j.plan[2] if j.plan else _lora.fit_iters(j.l)
         j.bits = quantizer.num_bits
         if j.right:
             j.W_s = W[j.lo:j.hi].contiguous()
@@ -176,94 +225,186 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
             j.s_s = j.s[j.lo:j.hi].contiguous() if j.s is not None else None
             sm_s = s_mask[j.lo:j.hi].contiguous()
         j.mask_s = ops.mask_nm(j.W_s, sm_s, prune_n, prune_m)
-        hist = torch.zeros(32768, dtype=torch.int32, device=dev)
-        ops.hist_abs(j.W_s, hist)
-        parallel.all_reduce(hist, group)
-        sf1 = _scale(hist, N * K, quantizer)
+        ops.hist_abs(j.W_s, hists[idx])
+    if describe:
+        for name, _, _ in items:
+            describe(name)
+    fan_out(local_mask)
+    parallel.all_reduce(hists, group)
+    mark("mask+hist")
+
+    # ---- phase 1b: first scale, error matrix, outlier columns, Gram contributions to the owners ----------------------------
+    def local_error(idx):
+        j = jobs[idx]
+        sf1 = _scale(hists[idx], j.N * j.K, quantizer)
         _, j.E_s = ops.error_matrix(j.W_s, j.mask_s, j.s_s, sf1.reshape(1), j.bits, deq_bf16=not quantizer.slim_quant)
         j.Et_s = ops.transpose(j.E_s)
         j.defl_rows = j.defl_dm = j.info_o = None
+    fan_out(local_error)
+    for j in jobs:
         if j.t:
-            _deflate(j, outliers, dev, group)
+            _deflate(j, j.outliers, dev, group)
+    mark("error+deflate")
+    # the linears an owner iterates on in lockstep: same size, same depth, same filter class
+    classes = {}
+    for idx, j in enumerate(jobs):
+        key = (j.owner, j.Dm, j.l, j.cond, j.plan[1] if j.plan else 0, j.n_iter)
+        classes.setdefault(key, []).append(idx)
+    Cb = {key: torch.empty(len(members), key[1], key[1], dtype=torch.bfloat16, device=dev)
+          for key, members in classes.items() if key[0] == rank}
+    slot = {idx: (key, b) for key, members in classes.items() for b, idx in enumerate(members)}
+
+    def local_gram(idx):
         # Gram contribution over the sharded dimension: E_s^T E_s [K, K] (row blocks) or E_s E_s^T [N, N] (column blocks)
+        j = jobs[idx]
         op = j.Et_s if j.right else j.E_s
-        Cp = ops.gemm_nt(op, op, out_f32=True)[0]
-        parallel.reduce(Cp, j.owner, group)
-        if rank == j.owner:
-            j.P, _, j.info = ops.gramfit_iterate(Cp.to(torch.bfloat16), j.l, _lora.fit_iters(j.l), seed=_lora.FIT_SEED, cond_e=j.cond)
+        key, b = slot[idx]
+        if world == 1:
+            ops.gemm_nt(op, op, C16=Cb[key][b])
         else:
-            j.P = torch.empty(j.Dm, j.l, dtype=torch.bfloat16, device=dev)
-            j.info = torch.zeros(64, dtype=torch.int32, device=dev)
-        del Cp
-    # ---- phase 2: the bases to everyone, projections, Rayleigh-Ritz matrices ----------------------------------------------
+            j.Cp = ops.gemm_nt(op, op, out_f32=True)[0]
+    fan_out(local_gram)
+    if world > 1:
+        for idx, j in enumerate(jobs):
+            parallel.reduce(j.Cp, j.owner, group)
+            if rank == j.owner:
+                key, b = slot[idx]
+                Cb[key][b].copy_(j.Cp)
+            del j.Cp
+
+    mark("gram")
+    # ---- phase 2: the owners' lockstep iterations; bases to everyone; projections; Rayleigh-Ritz matrices -----------------
+    keys = list(classes)
+    reports = {}
+
+    def iterate(c):
+        key = keys[c]
+        owner, Dm, l, cond, fbits, n_iter = key
+        members = classes[key]
+        if owner == rank:
+            plans = [jobs[i].plan for i in members]
+            ops.set_fit_filter([p[0][0] for p in plans] if plans[0] else [], fbits)
+            P, Pt, info, scal = ops.gramfit_iterate_batched(Cb.pop(key), l, n_iter, seed=_lora.FIT_SEED, cond_e=cond)
+            for b, i in enumerate(members):
+                jobs[i].P, jobs[i].Pt = P[b], Pt[b]
+            reports[key] = (info, scal)
+        else:
+            for i in members:
+                jobs[i].P, jobs[i].Pt = torch.empty(Dm, l, dtype=torch.bfloat16, device=dev), None
+    fan_out(iterate, len(keys))
+    mark("iterate")
+    sizes = {}
+    for idx, j in enumerate(jobs):
+        sizes.setdefault((j.l, j.rf), []).append(idx)
+    Ms = {k: torch.empty(len(m), k[0], k[0], dtype=torch.float32, device=dev) for k, m in sizes.items()}
+    where = {i: (k, b) for k, members in sizes.items() for b, i in enumerate(members)}
     for j in jobs:
         parallel.broadcast(j.P, j.owner, group)
+
+    def project(idx):
+        j = jobs[idx]
+        if j.Pt is None:
+            j.Pt = ops.transpose(j.P)
         # right: Z_s = E_s P [rows, l];  left: Z_s = E_s^T P [K_s, l]
-        j.Z, _, j.M = ops.gramfit_project(j.E_s if j.right else j.Et_s, ops.transpose(j.P))
-        parallel.all_reduce(j.M, group)
-    # ---- phase 3: the eigenproblems, every owner its own in one batched chain per size -------------------------------------
-    mine = {}
-    for i, j in enumerate(jobs):
-        if j.owner == rank:
-            mine.setdefault(j.l, []).append(i)
-    for l, idxs in sorted(mine.items()):
-        Mb = torch.stack([jobs[i].M for i in idxs]).contiguous()
-        d, e, Q = ops.tridiagonalize_batched(Mb)
-        tail = ops.eigh_tail(d, e, Q, Mb, max(jobs[i].rf for i in idxs))
-        for b, i in enumerate(idxs):
-            jobs[i].M = Mb[b].contiguous()
-            jobs[i].evals = d[b].contiguous()
-            jobs[i].info[61] = tail[b]
-    for j in jobs:
-        if j.owner != rank:
-            j.evals = torch.empty(j.l, dtype=torch.float32, device=dev)
-        parallel.broadcast(j.M, j.owner, group)         # its last rf rows hold the wanted eigenvectors
-        parallel.broadcast(j.evals, j.owner, group)
-    # ---- phase 4: factors, residual, second scale, re-quantisation, gather --------------------------------------------------
-    status = torch.zeros(len(jobs), 2, dtype=torch.int32, device=dev)
-    for idx, (j, (name, lin, wrapped)) in enumerate(zip(jobs, items)):
+        j.Z, _, M = ops.gramfit_project(j.E_s if j.right else j.Et_s, j.Pt)
+        k, b = where[idx]
+        Ms[k][b].copy_(M)
+    fan_out(project)
+    for k in sizes:
+        parallel.all_reduce(Ms[k], group)
+
+    mark("project")
+    # ---- phase 3: the Rayleigh-Ritz stage of every linear, on every rank from identical input ------------------------------
+    size_keys = list(sizes)
+
+    def ritz(c):
+        k = size_keys[c]
+        members = sizes[k]
+        evals, vecs, tail = _lora.rayleigh_ritz(Ms[k], k[1], [jobs[i].rank_ - jobs[i].t for i in members],
+                                                max(jobs[i].floor for i in members))
+        for b, i in enumerate(members):
+            jobs[i].evals, jobs[i].vecs, jobs[i].tail = evals[b], vecs[b], tail[b]
+    fan_out(ritz, len(size_keys))
+    mark("ritz")
+    status = torch.zeros(n, 4, dtype=torch.int32, device=dev)
+    for key, (info, scal) in reports.items():
+        members = classes[key]
+        # the owner's reports: conditioning against what the spectrum shows, measured spread, where the cut sits
+        ops.gramfit_check(torch.stack([jobs[i].evals for i in members]), jobs[members[0]].rf, key[3], scal, info)
+        for b, i in enumerate(members):
+            status[i, 0] = (info[b, :-3].ne(0).any() | jobs[i].tail.ne(0)).to(torch.int32)
+            status[i, 1:] = info[b, -3:].flip(0)
+
+    # ---- phase 4: factors, residual, second histograms (one all-reduce), re-quantisation, gather ---------------------------
+    hists.zero_()
+
+    def factors(idx):
+        j = jobs[idx]
         r8 = _lora._round_up8(j.rank_)
         nfit = j.rank_ - j.t
         # right: dm = lora_left [K, rf] (whole), rows = this block's rows of U;  left: dm = U [N, rf] (whole), rows = this
         # block's rows of lora_left
-        dm, _, rows, _, _ = ops.gramfit_factors(j.right, j.P, j.Z, j.M, j.evals, j.rf, s=j.s if j.right else j.s_s,
-                                                info=j.info, cond_e=j.cond)
-        rows_full = torch.zeros(rows.shape[0], r8, dtype=torch.bfloat16, device=dev)
-        dm_full = torch.zeros(j.Dm, r8, dtype=torch.bfloat16, device=dev)
-        if j.t:
-            rows_full[:, :j.t] = j.defl_rows[:, :j.t]
-            dm_full[:, :j.t] = j.defl_dm[:, :j.t]
-        rows_full[:, j.t:j.rank_] = rows[:, :nfit]
-        dm_full[:, j.t:j.rank_] = dm[:, :nfit]
+        dm, _, rows, _, _ = ops.gramfit_factors(j.right, j.P, j.Z, j.vecs, j.evals, j.rf, s=j.s if j.right else j.s_s)
+        if j.t == 0 and r8 == j.rf:
+            rows_full, dm_full = rows, dm
+            if j.rank_ != r8:
+                rows_full[:, j.rank_:] = 0
+                dm_full[:, j.rank_:] = 0
+        else:
+            rows_full = torch.zeros(rows.shape[0], r8, dtype=torch.bfloat16, device=dev)
+            dm_full = torch.zeros(j.Dm, r8, dtype=torch.bfloat16, device=dev)
+            if j.t:
+                rows_full[:, :j.t] = j.defl_rows[:, :j.t]
+                dm_full[:, :j.t] = j.defl_dm[:, :j.t]
+            rows_full[:, j.t:j.rank_] = rows[:, :nfit]
+            dm_full[:, j.t:j.rank_] = dm[:, :nfit]
+        j.rows_full, j.dm_full = rows_full, dm_full
         U_s, L_s = (rows_full, dm_full) if j.right else (dm_full, rows_full)
-        Wn_s = ops.lowrank_residual(U_s, L_s, j.W_s, j.mask_s)                      # lora.py:199-201
-        hist = torch.zeros(32768, dtype=torch.int32, device=dev)
-        ops.hist_abs(Wn_s, hist)
-        parallel.all_reduce(hist, group)
-        sf2 = _scale(hist, j.N * j.K, quantizer)
-        Wq_s = ops.fake_quant_pt(Wn_s, sf2.reshape(1), j.bits)                      # lora.py:202-204
-        lin.weight.data = _gather_blocks(Wq_s, j.bounds, 0 if j.right else 1, group)
-        rows_all = _gather_blocks(rows_full, j.bounds, 0, group)
-        U, L = (rows_all, dm_full) if j.right else (dm_full, rows_all)
-        sf_out = (sf2 if quantizer.slim_quant else sf2.to(torch.bfloat16)).reshape(1, 1)
-        quantizer.scaling_factor = sf_out
+        j.Wn_s = ops.lowrank_residual(U_s, L_s, j.W_s, j.mask_s)                    # lora.py:199-201
+        ops.hist_abs(j.Wn_s, hists[idx])
+    fan_out(factors)
+    for idx, j in enumerate(jobs):
+        if j.info_o is not None:
+            status[idx, 0] |= j.info_o.ne(0).any().to(torch.int32)
+    parallel.all_reduce(hists, group)
+    parallel.all_reduce(status, group, op="max")
+    mark("factors")
+
+    def requantise(idx):
+        j = jobs[idx]
+        j.sf2 = _scale(hists[idx], j.N * j.K, quantizer)
+        j.Wq_s = ops.fake_quant_pt(j.Wn_s, j.sf2.reshape(1), j.bits)                # lora.py:202-204
+    fan_out(requantise)
+    mark("requant")
+    for j in jobs:                                                                   # (collectives: one order on every rank)
+        j.W_all = _gather_blocks(j.Wq_s, j.bounds, 0 if j.right else 1, group)
+        j.rows_all = _gather_blocks(j.rows_full, j.bounds, 0, group)
+
+    def attach(idx):
+        j = jobs[idx]
+        name, lin, wrapped = items[idx]
+        lin.weight.data = j.W_all
+        U, L = (j.rows_all, j.dm_full) if j.right else (j.dm_full, j.rows_all)
+        sf_out = (j.sf2 if quantizer.slim_quant else j.sf2.to(torch.bfloat16)).reshape(1, 1)
         lin.scaling_factor = sf_out
         lin.lora_rank = torch.tensor(j.rank_)
-        sq = torch.sqrt(lin.lora_rank)
+        sq = float(j.rank_) ** 0.5
         lin.lora_left = torch.nn.Parameter(L[:, :j.rank_].contiguous() * sq)
         lin.lora_right = torch.nn.Parameter(ops.transpose(U)[:j.rank_].contiguous() * sq)
-        lin.register_forward_hook(add_lora_hook)
-        bad = j.info[:-3].ne(0).any()
-        if j.info_o is not None:
-            bad = bad | j.info_o.ne(0).any()
-        status[idx, 0] = bad.to(torch.int32)
-        status[idx, 1] = j.info[-1]
-    parallel.all_reduce(status, group, op="max")
-    for idx, (name, lin, wrapped) in enumerate(items):
         info = torch.zeros(64, dtype=torch.int32, device=dev)
         info[0] = status[idx, 0]
-        info[-1] = status[idx, 1]
+        info[-3:] = status[idx, 1:].flip(0)
         lin.lora_fit_info = info
+        j.left, j.right_t, j.info_out, j.sf_out = lin.lora_left.data, lin.lora_right.data, info, sf_out
+    fan_out(attach)
+    mark("gather+attach")
+    if trace:
+        torch.cuda.synchronize()
+        for (_, e0, h0), (name, e1, h1) in zip(marks, marks[1:]):
+            print(f"[shard] {name}: gpu {e0.elapsed_time(e1):.2f} ms, host reached it at {h1:.2f} ms", flush=True)
+    for idx, (name, lin, wrapped) in enumerate(items):
+        quantizer.scaling_factor = lin.scaling_factor
+        lin.register_forward_hook(add_lora_hook)
         if callback is not None:
             callback(name, lin, wrapped)
     return status

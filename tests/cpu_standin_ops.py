@@ -23,6 +23,22 @@ def transpose(x, out=None):
     return x.t().contiguous()
 
 
+def gram_accum(x, H, nsamples_before, batch):
+    """sparsegpt.py:36-39 in place (bf16 products are exact in fp32; fp32 accumulation)."""
+    new, _ = O.add_batch_gram(H, nsamples_before, x.reshape(batch, -1, x.shape[-1]))
+    H.copy_(new)
+    return H
+
+
+def scaler_row_accum(x, scaler_row, nsamples_before, n_chunks=1, batch_per_chunk=1):
+    """layerwrapper.py:25-41 in place, one update per chunk."""
+    n = nsamples_before
+    for chunk in x.reshape(n_chunks, -1, x.shape[-1]):
+        new, n = O.add_batch_scaler_row(scaler_row, n, chunk.reshape(batch_per_chunk, -1, x.shape[-1]))
+        scaler_row.copy_(new)
+    return scaler_row
+
+
 def mask_nm(W, s, n, m):
     return O.prune_nm(W.abs() * s.reshape(1, -1), n, m)               # slim/utils.py:75-88 on |W| * sqrt(scaler_row)
 
@@ -76,8 +92,11 @@ def error_matrix(W, mask, s, sf, num_bits, want_f32=False, want_bf16=True, out=N
     return (E.float() if want_f32 else None), E.to(BF16)
 
 
-def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False):
+def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False, C16=None):
     C = alpha * (A.float() @ Bt.float().t())
+    if C16 is not None:
+        C16.copy_(C)
+        out_bf16 = True
     return (C if out_f32 else None), (C.to(BF16) if out_bf16 else None), (C.to(BF16).t().contiguous() if out_t else None)
 
 
@@ -106,6 +125,30 @@ def gramfit_iterate(C16, l, n_iter, seed=0, flags=0, cond_e=0):
     w, V = torch.linalg.eigh(C16.double())
     P = V[:, -l:].to(BF16).contiguous()
     return P, P.t().contiguous(), torch.zeros(64, dtype=torch.int32)
+
+
+def gramfit_iterate_batched(C16, l, n_iter, seed=0, flags=0, cond_e=0):
+    outs = [gramfit_iterate(C, l, n_iter, seed, flags, cond_e) for C in C16]
+    B = len(outs)
+    return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), torch.zeros(B, 64, dtype=torch.int32),
+            torch.zeros(B, 4))
+
+
+def fit_subspace(N, K, r, oversample):
+    l = min(r + oversample, N, K)
+    return l - l % 8
+
+
+def set_fit_filter(ratios, bits):
+    pass            # (the stand-in iteration is exact: nothing to filter)
+
+
+def gramfit_check(evals, r, cond_e, scal, info):
+    return info     # (exact stand-ins: no conditioning to report)
+
+
+def ritz_split_supported(l, drop_max):
+    return False    # (the stand-in Rayleigh-Ritz stage is the exact eigen-decomposition below)
 
 
 def gramfit_project(X, Pt):

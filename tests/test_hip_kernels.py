@@ -74,6 +74,54 @@ def test_gram(ops, golden):
     torch.testing.assert_close(torch.diag(H2).cpu() / 2, sr.cpu(), rtol=1e-5, atol=0)
 
 
+def test_wrapper_collects_gram_and_two_shares_combine(ops, golden):
+    """WrappedGPT(collect_gram=True): the reference's H (slim/sparsegpt.py:28-39, fixture from the reference) from the hook's
+    own calls; and two wrappers that saw 1 and 3 of the 4 samples combine through reduce_gram (the all-reduce stood in for by
+    a sum over the two) into the same matrix."""
+    from slim_amd.layerwrapper import WrappedGPT
+    g = golden("g1_stats")
+    X = g2d(g["X"])                                                   # [4, 1, 16, 64]
+    lin = torch.nn.Linear(64, 32, bias=False).to(torch.bfloat16).to(DEV)
+    w = WrappedGPT(lin, collect_gram=True)
+    for j in range(4):
+        w.add_batch(X[j], None)
+    scale = float(g["H"].abs().max())
+    torch.testing.assert_close(w.H.cpu(), g["H"], rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(w.scaler_row.cpu(), g["scaler_row"], rtol=3e-6, atol=0)
+    a, b = WrappedGPT(lin, collect_gram=True), WrappedGPT(lin, collect_gram=True)
+    a.add_batch(X[0], None)
+    b.add_batch(X[1:].reshape(3, 16, 64), None, per_sample=True)
+    pending = {}
+    # the two "ranks" in lockstep: counts first, then the matrices (the order reduce_gram issues them in)
+    import threading
+    barrier = threading.Barrier(2)
+
+    def run(wr):
+        def reduce(t):
+            with lock:
+                key = (t.dtype, tuple(t.shape))
+                slot = pending.setdefault(key, [])
+                slot.append(t)
+            barrier.wait()
+            with lock:
+                if key in pending and len(pending[key]) == 2:
+                    x, y = pending.pop(key)
+                    total = x + y
+                    x.copy_(total)
+                    y.copy_(total)
+            barrier.wait()
+            return t
+        wr.reduce_gram(reduce)
+    lock = threading.Lock()
+    ts = [threading.Thread(target=run, args=(wr,)) for wr in (a, b)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert a.gram_nsamples == b.gram_nsamples == 4 and torch.equal(a.H, b.H)
+    torch.testing.assert_close(a.H.cpu(), g["H"], rtol=1e-5, atol=1e-5 * scale)
+
+
 def test_shift_zeros_sqrt(ops, golden):
     g = golden("g2_shift_zeros")
     for a, b in (("v", "out"), ("v2", "out2"), ("v3", "out3")):

@@ -77,3 +77,72 @@ def test_exchange_world_size_2_gloo():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2] and set(res[0][2]) == {0, 1}
+
+
+# ---- token-sharded calibration Gram matrix -----------------------------------------------------------------------------
+def _gram_inputs():
+    g = torch.Generator().manual_seed(77)
+    scale = torch.exp(torch.randn(48, generator=g) * 0.5)
+    return (torch.randn(6, 40, 48, generator=g) * scale).to(torch.bfloat16)          # 6 samples of 40 tokens, K = 48
+
+
+def _gram_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_standin_ops as standin
+    import slim_amd.layerwrapper as LW
+    from slim_amd import parallel
+    LW.ops = standin                                         # (no GPU here: the kernels' CPU stand-ins, same arithmetic)
+    X = _gram_inputs()
+    # an uneven split of the samples: rank 0 takes four (in two forward calls), rank 1 two (one at a time)
+    mine = [X[0:3], X[3:4]] if rank == 0 else [X[4:5], X[5:6]]
+    w = LW.WrappedGPT(torch.nn.Linear(48, 16, bias=False).to(torch.bfloat16), collect_gram=True)
+    for chunk in mine:
+        w.add_batch(chunk, None, per_sample=True)
+    local_n = w.gram_nsamples
+    w.reduce_gram(parallel.all_reduce)
+    q.put((rank, local_n, w.gram_nsamples, w.H.clone(), w.scaler_row.clone(), w.nsamples))
+    dist.destroy_process_group()
+
+
+def test_token_sharded_gram_matches_one_rank():
+    """WrappedGPT(collect_gram=True) on two ranks, each folding its share of the samples, then reduce_gram (one all-reduce
+    SUM of the count-weighted matrices): equal to one rank folding all samples (slim/sparsegpt.py:28-39) within 1e-5, and to
+    the oracle's recurrence over the samples one at a time."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_standin_ops as standin
+    import slim_amd.layerwrapper as LW
+    from oracle import slim_oracle as O
+    X = _gram_inputs()
+    real = LW.ops
+    LW.ops = standin
+    try:
+        one = LW.WrappedGPT(torch.nn.Linear(48, 16, bias=False).to(torch.bfloat16), collect_gram=True)
+        one.add_batch(X, None, per_sample=True)
+        assert one.reduce_gram(None) is one.H and one.gram_nsamples == 6
+        with pytest.raises(ValueError):
+            LW.WrappedGPT(torch.nn.Linear(48, 16, bias=False).to(torch.bfloat16)).reduce_gram(None)
+    finally:
+        LW.ops = real
+    Href, n = torch.zeros(48, 48), 0
+    for j in range(6):
+        Href, n = O.add_batch_gram(Href, n, X[j])
+    scale = float(Href.abs().max())
+    torch.testing.assert_close(one.H, Href, rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(torch.diag(one.H) / 2, one.scaler_row, rtol=1e-5, atol=0)      # diag(H) / 2 == scaler_row
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gram_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [4, 2] and all(r[2] == 6 for r in res)
+    assert torch.equal(res[0][3], res[1][3])                                       # the same matrix on both ranks
+    torch.testing.assert_close(res[0][3], one.H, rtol=1e-5, atol=1e-5 * scale)
+    # (scaler_row stays the rank's own: the sharded driver gathers the per-sample sums instead, see gather_sample_stats)
+    assert res[0][5] == 4 and res[1][5] == 2

@@ -68,14 +68,15 @@ def _make_items():
 
 def _compress(items, world_expected):
     import cpu_standin_ops as standin
-    from slim_amd import sharded, parallel
+    from slim_amd import sharded, parallel, lora
     from slim_amd.quantization.quantization import Quantizer
     sharded.ops = standin
+    lora.ops = standin          # (the Rayleigh-Ritz stage is lora.rayleigh_ritz)
     q = Quantizer("weight", num_bits=4, slim_quant=True)
     assert parallel.world_info()[1] == world_expected
     assert sharded.supported(items, world_expected, 2, 4, q, 0.25, True, False, True, True, None)
     status = sharded.compress_linears_sharded(items, torch.device("cpu"), 2, 4, q, 0.25, True, None)
-    assert int(status.abs().sum()) == 0
+    assert int(status[:, :2].abs().sum()) == 0
     out = {}
     for name, lin, w in items:
         assert len(lin._forward_hooks) == 1 and int(lin.lora_rank) == lin.lora_left.shape[1] == lin.lora_right.shape[0]

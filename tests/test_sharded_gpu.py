@@ -121,7 +121,8 @@ def test_sharded_matches_single_gpu(tmp_path, quant, port):
         for label, b in (("one rank", alone[name]), ("two ranks, rank 0", two[0][name]), ("two ranks, rank 1", two[1][name])):
             assert b["hooks"] == 1 and b["rank"] == a["rank"] and b["L"].shape == a["L"].shape and b["R"].shape == a["R"].shape
             assert b["sf_dtype"] == a["sf_dtype"] == ("torch.float32" if quant == "slim" else "torch.bfloat16")
-            assert int(b["info"].abs().sum()) == 0, (name, label, b["info"])
+            # (the last three words are the fit's reports -- nothing to repeat; measured spread; where the cut sits -- not errors)
+            assert int(b["info"][:-3].abs().sum()) == 0 and int(b["info"][-1]) == 0, (name, label, b["info"])
             assert bool((b["weight"][b["mask"]] == 0).all()) and bool((a["weight"][a["mask"]] == 0).all())
             assert torch.equal(a["mask"], b["mask"])
             # kept entries: the same 4-bit level except where the slightly different factors tip a rounding
@@ -198,7 +199,7 @@ def test_sharded_code_path_at_13b_shape_within_1e3_of_truncated_svd():
     items = [("down_proj", lin, w)]
     assert sharded.supported(items, 8, 2, 4, q, 0.1, True, False, True, True, 256)      # 108 aligned column blocks for 8 ranks
     status = sharded.compress_linears_sharded(items, torch.device(DEV), 2, 4, q, 0.1, True, 256)
-    assert int(status.abs().sum()) == 0
+    assert int(status[:, :2].abs().sum()) == 0              # (columns 2, 3: the measured spread and where the cut sits)
     assert int(lin.lora_rank) == rank and lin.lora_left.shape == (K, rank) and lin.lora_right.shape == (rank, N)
     mask = ops.mask_nm(W0, s, 2, 4)
     sf1 = ops.quant_search(ops.hist_abs(W0), 20000, 4)[2].reshape(1)
