@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(F32GemmArgs g) {
         float v[4];
         f32x4 d1 = f32x4{0.f, 0.f, 0.f, 0.f}, d2 = d1;
         if (g.coef && g.D1) d1 = *(const f32x4*)(g.D1 + (int64_t)row * g.ldc + col);
-        if (g.coef && g.D2) d2 = *(const f32x4*)(g.D2 + (int64_t)row * g.ldc + col);
+        if (g.coef && g.D2 && !g.coef_diag) d2 = *(const f32x4*)(g.D2 + (int64_t)row * g.ldc + col);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float a = T[r * 65 + c + u];
-            if (g.coef) v[u] = c0 * a + c1 * d1[u] + c2 * d2[u];
+            if (g.coef) v[u] = c0 * a + c1 * d1[u] + c2 * (g.coef_diag ? (row == col + u ? 1.f : 0.f) : d2[u]);
             else v[u] = g.poly_G ? g.pb * gin[it][u] + g.pq * a + (row == col + u ? g.pa : 0.f) : g.alpha * a;
         }
         *(f32x4*)(g.C + (int64_t)row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};

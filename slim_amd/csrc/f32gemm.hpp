@@ -32,6 +32,7 @@ struct F32GemmArgs {
     const float* D1 = nullptr;
     const float* D2 = nullptr;
     int64_t sD1 = 0, sD2 = 0;
+    int coef_diag = 0;  // != 0: the third term is coef[2] * I (square products) instead of coef[2] * D2
     // optional scale in device memory: the product is divided by x * x, x = inv_sq_scale[p * iss_stride]
     const float* inv_sq_scale = nullptr;
     int iss_stride = 0;

@@ -31,7 +31,7 @@
 #define RS_WAVES 16
 #define RS_MAX_C (RS_CPW * RS_WAVES)
 #define RS_SQUARINGS_SMALL 4
-#define RS_SCAL 16                      // floats of per-problem scalars
+#define RS_SCAL 24                      // floats of per-problem scalars
 #define CHK(x)                 \
     do {                       \
         int rc__ = (x);        \
@@ -42,7 +42,8 @@ struct RsKeep {
     int c[RS_MAX_BATCH];                // vectors to drop per problem (l - keep)
 };
 
-enum { SC_S = 0, SC_N3 = 1, SC_B = 2, SC_A = 3, SC_CA = 4, SC_ONE = 7, SC_CB = 8, SC_LO = 12, SC_HI = 13 };      // SC_ONE: {1, *, *}
+// SC_ONE: {1, *, *};  SC_T2: T_2(X) = 2 X^2 - I as coefficients of {M M, M, I};  SC_TWO: {2, 0, -1}
+enum { SC_S = 0, SC_N3 = 1, SC_B = 2, SC_A = 3, SC_CA = 4, SC_ONE = 7, SC_CB = 8, SC_LO = 12, SC_HI = 13, SC_T2 = 16, SC_TWO = 20 };
 
 // Sum over the 64 lanes, the result in every lane: data-parallel-primitive moves inside the rows of 16 lanes and two row
 // broadcasts instead of six trips through the LDS crossbar (the QR kernel's critical path is a chain of these sums).
@@ -293,6 +294,10 @@ __global__ __launch_bounds__(1024) void rs_bounds_kernel(const float* __restrict
         sc[SC_CA] = ih, sc[SC_CA + 1] = -mid * ih, sc[SC_CA + 2] = 0.f;
         sc[SC_ONE] = 1.f;
         sc[SC_CB] = 2.f * ih, sc[SC_CB + 1] = -2.f * mid * ih, sc[SC_CB + 2] = -1.f;
+        // X = p M + q I with p = 1 / half, q = -mid / half:  T_2(X) = 2 X^2 - I = 2 p^2 M M + 4 p q M + (2 q^2 - 1) I
+        const float q = -mid * ih;
+        sc[SC_T2] = 2.f * ih * ih, sc[SC_T2 + 1] = 4.f * ih * q, sc[SC_T2 + 2] = 2.f * q * q - 1.f;
+        sc[SC_TWO] = 2.f, sc[SC_TWO + 1] = 0.f, sc[SC_TWO + 2] = -1.f;
         if (c > 0) sc[SC_LO] = tr / (float)c;        // mean Rayleigh quotient of the block: where the dropped eigenvalues sit
     }
 }
@@ -503,6 +508,12 @@ extern "C" int64_t slim_ritz_split_workspace_bytes(int l, int drop_max, int batc
     return rs_ws(nullptr, l, (drop_max + 3) & ~3, batch < RS_MAX_BATCH ? batch : RS_MAX_BATCH).total;
 }
 
+// SLIM_RS_STRIDE4=0: every Chebyshev step as a launch of its own (A/B aid)
+static const bool g_stride4 = [] {
+    const char* v = getenv("SLIM_RS_STRIDE4");
+    return !(v && v[0] == '0');
+}();
+
 static int rs_run(const float* M, int l, int nb, int top, const int32_t* keep_h, const int* degs, int ndeg, float* vecs, float* evals,
                   int32_t* info, char* ws_base, hipStream_t st) {
     RsKeep keep;
@@ -573,20 +584,45 @@ static int rs_run(const float* M, int l, int nb, int top, const int32_t* keep_h,
         for (int r = 0; r < ndeg; ++r) {
             // Chebyshev recurrence of degree degs[r] on the rows of Y[cur]
             int y0 = cur, y1 = (cur + 1) % 3;
-            {
-                SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
-                rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y0], M, l, c_pad, w.scal + SC_CA, RS_SCAL, w.Y[y0], nullptr, w.Y[y1]);
-                SLIM_LAUNCH_CHECK();
-            }
-            for (int k = 2; k <= degs[r]; ++k) {
-                const int y2 = 3 - y0 - y1;
+            if (degs[r] % 4 == 0 && g_stride4) {
+                // T_(m+n) = 2 T_m T_n - T_|m-n|: with P = T_4(X) formed once per round (two l x l products: T_2 = 2 X^2 - I,
+                // T_4 = 2 T_2^2 - I) the blocks Z_j = T_(4j)(X) Y obey the same recurrence, Z_(j+1) = 2 Z_j P - Z_(j-1),
+                // in a quarter of the launches (each is latency-bound: a skinny product at the launch floor)
+                F32GemmArgs g = gemm(M, sM, l, l, M, sM, l, 1, l, l, w.P[1], sM, l);
+                g.coef = w.scal + SC_T2, g.coef_stride = RS_SCAL, g.D1 = M, g.sD1 = sM, g.coef_diag = 1;
+                CHK(slim_f32gemm_launch(g, st));
+                g = gemm(w.P[1], sM, l, l, w.P[1], sM, l, 1, l, l, w.P[0], sM, l);
+                g.coef = w.scal + SC_TWO, g.coef_stride = RS_SCAL, g.coef_diag = 1;
+                CHK(slim_f32gemm_launch(g, st));
+                for (int k = 1; k <= degs[r] / 4; ++k) {
+                    SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
+                    if (k == 1) {
+                        rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y0], w.P[0], l, c_pad, w.scal + SC_ONE, RS_SCAL, nullptr, nullptr, w.Y[y1]);
+                        SLIM_LAUNCH_CHECK();
+                    } else {
+                        const int y2 = 3 - y0 - y1;
+                        rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y1], w.P[0], l, c_pad, w.scal + SC_TWO, RS_SCAL, nullptr, w.Y[y0], w.Y[y2]);
+                        SLIM_LAUNCH_CHECK();
+                        y0 = y1;
+                        y1 = y2;
+                    }
+                }
+            } else {
                 {
                     SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
-                    rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y1], M, l, c_pad, w.scal + SC_CB, RS_SCAL, w.Y[y1], w.Y[y0], w.Y[y2]);
+                    rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y0], M, l, c_pad, w.scal + SC_CA, RS_SCAL, w.Y[y0], nullptr, w.Y[y1]);
                     SLIM_LAUNCH_CHECK();
                 }
-                y0 = y1;
-                y1 = y2;
+                for (int k = 2; k <= degs[r]; ++k) {
+                    const int y2 = 3 - y0 - y1;
+                    {
+                        SLIM_PROF("rs_cheb", st, 4.0 * nb * ((double)l * l + 3.0 * c_pad * l), 2.0 * nb * c_pad * (double)l * l);
+                        rs_cheb_kernel<<<cheb_grid, 256, cheb_lds, st>>>(w.Y[y1], M, l, c_pad, w.scal + SC_CB, RS_SCAL, w.Y[y1], w.Y[y0], w.Y[y2]);
+                        SLIM_LAUNCH_CHECK();
+                    }
+                    y0 = y1;
+                    y1 = y2;
+                }
             }
             {
                 SLIM_PROF("rs_qr", st, 8.0 * nb * c_pad * l, 4.0 * nb * (double)c_pad * c_pad * l);
