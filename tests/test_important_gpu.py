@@ -246,3 +246,22 @@ def test_no_adapters_with_important_columns_raises_like_the_reference(ops, golde
     with pytest.raises(AttributeError, match="scaler_row"):
         P.prune_and_quantize(model, None, nsamples=8, bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5,
                              sparsity_type="2:4", quantize_weight=True, lora_rank=0., scale_important_weights=True)
+
+
+def test_packed_form_refuses_half_levels(ops):
+    """A weight compressed with scale_important_weights carries, in the flagged columns, levels of half the step (k / (2 sf)):
+    it is not a 4-bit code of the layer's scale, and the 2:4 int4 packing (pack_model, the multi-GPU exchange) must say so
+    instead of storing the nearest level."""
+    g = torch.Generator().manual_seed(3)
+    N, K, sf = 128, 256, 64.0
+    codes = torch.randint(-8, 8, (N, K), generator=g).float()
+    keep = torch.zeros(N, K // 4, 4, dtype=torch.bool)
+    keep[:, :, :2] = True                                             # two of every four input channels kept
+    W = (codes * keep.reshape(N, K) / sf).to(torch.bfloat16).to(DEV)
+    scale = torch.tensor([sf], device=DEV)
+    vals, meta = ops.pack24(W, scale)                                 # plain levels: fine
+    assert torch.equal(ops.unpack24(vals, meta, scale, N, K), W)
+    W2 = W.clone()
+    W2[:, 0] = (3.5 / sf)                                             # an odd multiple of half a step, as a doubled column leaves
+    with pytest.raises(ValueError, match="not 4-bit quantisation levels"):
+        ops.pack24(W2, scale)
