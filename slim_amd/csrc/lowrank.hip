@@ -163,8 +163,12 @@ __global__ void cond_check_kernel(const float* __restrict__ evals, int l, int r,
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const int cond_e = levels & 0xff, later = (levels >> 8) & 0xff;
-    // ascending eigenvalues; the weakest direction that still matters sits halfway into the oversampling part
-    const float hi = evals[(int64_t)b * l + l - 1], lo = evals[(int64_t)b * l + (l - r) / 2];
+    // ascending eigenvalues; the weakest direction that still matters sits halfway into the oversampling part.  A filtered
+    // iteration damps that part of the subspace (its Ritz values there say nothing about the matrix): the largest dropped
+    // eigenvalue, just below the rank, stands in -- on the flat spectra of these matrices the two lie within a few per cent
+    const float hi = evals[(int64_t)b * l + l - 1];
+    float lo = evals[(int64_t)b * l + (l - r) / 2];
+    if (scal && scal[b * SCAL_STRIDE + 2] > 0.f && l - r - 1 >= 0) lo = evals[(int64_t)b * l + l - r - 1];
     int need = 0, found = 0;
     if (hi > 0.f) {
         const float c = lo > 0.f ? log2f(hi / lo) : 200.f, lg = 0.5f * c;

@@ -88,6 +88,8 @@ def hint_level(hint):
 FIT_FILTER = os.environ.get("SLIM_FIT_FILTER", "1") == "1"
 FIT_FILTER_ROUNDS = int(os.environ.get("SLIM_FIT_FILTER_ROUNDS", "3"))
 FIT_FILTER_MARGIN = float(os.environ.get("SLIM_FIT_FILTER_MARGIN", "0.8"))
+FIT_FILTER_BITS_STEP = int(os.environ.get("SLIM_FIT_FILTER_BITS_STEP", "2"))
+FIT_FILTER_BITS_MIN = int(os.environ.get("SLIM_FIT_FILTER_BITS_MIN", "10"))
 
 
 def filter_plan(hints, floor=0):
@@ -103,7 +105,7 @@ def filter_plan(hints, floor=0):
     # largest eigenvalue over the interval's end: the measured spread (word / 4 = log2), 5 % slack, the margin
     kappa = max(2.0 ** (((h >> 8) & 0xff) / 4.0) for h in hints) * 1.05 / FIT_FILTER_MARGIN      # (the cut lies above `lo`)
     bits = int(math.ceil(math.log2(2.0 * (2.0 * kappa - 1.0) ** 2 - 1.0) + 0.5))
-    bits += bits & 1            # (even: fits in lockstep must agree on it, see planned_fit_group, and coarser classes agree more often)
+    bits = -(-max(bits, FIT_FILTER_BITS_MIN) // FIT_FILTER_BITS_STEP) * FIT_FILTER_BITS_STEP      # (classes: fits in lockstep must agree on it, see planned_fit_group)
     return ratios, max(2, min(bits, 12)), 2 * FIT_FILTER_ROUNDS - 1
 
 
@@ -160,6 +162,20 @@ def _assemble(N, K, rank, t, s, fitU, fitUt, fitL, fit_info, UO=None, Ct=None, i
 FIT_RITZ_SPLIT = os.environ.get("SLIM_FIT_RITZ_SPLIT", "1") == "1"
 
 
+def filter_levels(bits):
+    """The `ns_steps` argument of a filtered fit of class `bits` (filter_plan): its orthonormalisations are sized by the
+    class alone, so the word only tells the fit's own check what the class covers -- bits 8-15: the largest log2 spread
+    of eigenvalues inside the subspace the class was sized for (a fit that finds more than that asks to be repeated);
+    bits 0-7: the same, capped (unused by a filtered fit).  A function of the class only: the members of a lockstep
+    chain share it whatever their own estimates say."""
+    import math
+    kappa = (math.sqrt((2.0 ** (bits - 0.5) + 1.0) / 2.0) + 1.0) / 2.0         # inverts bits = log2(2 (2 kappa - 1)^2 - 1) + 0.5
+    # (the check asks for a repeat above covered + 0.5: half a level to a level and a half of tolerance, which the margins of
+    # the Newton-Schulz schedules and the extra levels of a fit's last orthonormalisation absorb)
+    covered = int(max(1, min(12, math.ceil(math.log2(max(kappa * FIT_FILTER_MARGIN / 1.05, 2.0))))))
+    return min(6, covered) | (covered << 8)
+
+
 def ritz_split_applies(l, drop, floor=0):
     """Whether the Rayleigh-Ritz step of a fit with subspace dimension l that drops `drop` directions goes through
     ops.ritz_split.  Only while the dropped subspace is a small part of the whole (at most a quarter: l = 576, 64 to 80
@@ -207,7 +223,8 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0, floor=0)
         M = torch.empty(1, l, l, dtype=torch.float32, device=E.device)
         plan = filter_plan([hint], floor)
         ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
-        ctx = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M[0], **_fit_kwargs(spread, True, hint, floor))
+        ctx = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M[0],
+                                    **_fit_kwargs(spread, True, hint, floor, plan))
         evals, vecs, info = rayleigh_ritz(M, rf, [rank - t], floor)
         fit = ops.lowrank_fit_back(ctx, evals, None, None, vecs, s=s, tail_info=info)
     else:
@@ -217,10 +234,10 @@ def fit_error_matrix(E, Et, rank, s, outliers=None, spread=1.0, hint=0, floor=0)
     return _assemble(N, K, rank, t, s, fit["U"], fit["Ut"], fit["L"], fit["info"], UO, Ct, info_o)
 
 
-def _fit_kwargs(spread, sketch_split=True, hint=0, floor=0):
+def _fit_kwargs(spread, sketch_split=True, hint=0, floor=0, plan=None):
     return dict(seed=FIT_SEED, flags=ops.fit_flags(FIT_CHOLESKY_QR, FIT_LIBRARY_EIGH,
                                                     FIT_SKETCH_SPLIT and sketch_split),
-                ns_steps=fit_ns_steps(spread, hint, floor))
+                ns_steps=filter_levels(plan[1]) if plan else fit_ns_steps(spread, hint, floor))
 
 
 def fit_plan(N, K, rank, outliers=None):
@@ -250,7 +267,7 @@ def fit_error_matrix_front(E, Et, rank, outliers, spread, M_out, sketch_split=Tr
     plan = filter_plan([hint], floor) if l < min(N, K) else None
     ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
     p["ctx"] = ops.lowrank_fit_front(E, Et, rf, over, plan[2] if plan else fit_iters(l), M_out,
-                                     **_fit_kwargs(spread, sketch_split, hint, floor))
+                                     **_fit_kwargs(spread, sketch_split, hint, floor, plan))
     return p
 
 
@@ -290,7 +307,7 @@ def fit_error_matrix_front_group(Es, Ets, ranks, outliers, spread, M_out, sketch
     plan = filter_plan(hints if hints is not None else [hint] * B, floor)
     ops.set_fit_filter(*(plan[:2] if plan else ([], 0)))
     p["ctx"] = ops.lowrank_fit_front_group(Eds, Etds, rf, over, plan[2] if plan else fit_iters(l), M_out,
-                                           **_fit_kwargs(spread, sketch_split, hint, floor))
+                                           **_fit_kwargs(spread, sketch_split, hint, floor, plan))
     return p
 
 
@@ -554,7 +571,7 @@ def planned_fit_group(module, rank_ratio, lora_tile_size, slim_lora, activations
     # member's arithmetic is part of the key, so that a layer's result does not depend on which layers share its chain:
     # several ranks dealing the layers of a block among themselves produce what one rank does)
     plan = filter_plan([hint], floor)
-    return (min(N, K), rf, over, fit_ns_steps(spread, 0 if plan else hint, floor), plan[1] if plan else 0, shape), l
+    return (min(N, K), rf, over, filter_levels(plan[1]) if plan else fit_ns_steps(spread, hint, floor), plan[1] if plan else 0, shape), l
 
 
 def fit_keep(c):
@@ -569,8 +586,8 @@ def add_lora_fit_front_group(ctxs, M_out, sketch_split=True):
     for c in ctxs:
         c.touch()
     floor = max(c.cond_floor for c in ctxs)
-    filtered = filter_plan([c.level_hint for c in ctxs], floor) is not None
-    if len({fit_ns_steps(c.spread, 0 if filtered else c.level_hint, floor) for c in ctxs}) != 1:
+    plans = [filter_plan([c.level_hint], floor) for c in ctxs]
+    if len({(filter_levels(p[1]), p[1]) if p else fit_ns_steps(c.spread, c.level_hint, floor) for c, p in zip(ctxs, plans)}) != 1:
         raise ValueError("the layers of a group must share their Newton-Schulz depth")
     ctxs[0].pending = fit_error_matrix_front_group([c.E for c in ctxs], [c.Et for c in ctxs], [c.rank for c in ctxs],
                                                    [c.outliers for c in ctxs], ctxs[0].spread, M_out, sketch_split,

@@ -214,7 +214,8 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         j.hint = int(getattr(wrapped, "fit_level_hint", 0) or 0)
         j.floor = int(getattr(wrapped, "fit_cond_floor", 0) or 0)
         j.plan = _lora.filter_plan([j.hint], j.floor)
-        j.cond = _lora.fit_ns_steps(wrapped.scale_spread if use_slim else 1.0, 0 if j.plan else j.hint, j.floor)
+        j.cond = (_lora.filter_levels(j.plan[1]) if j.plan
+                  else _lora.fit_ns_steps(wrapped.scale_spread if use_slim else 1.0, j.hint, j.floor))
         j.n_iter = j.plan[2] if j.plan else _lora.fit_iters(j.l)
         j.bits = quantizer.num_bits
         if j.right:
