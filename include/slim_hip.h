@@ -412,6 +412,10 @@ int64_t slim_lora_finish_workspace_bytes(int64_t N, int64_t K);
 int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t K, int r8, int rank, const void* W_bf16,
                      const uint8_t* mask, int quant_mode, int num_bits, int prescale, void* W_out_bf16, float* sf_out,
                      void* lora_left_out, void* lora_right_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* The last step of slim_lora_finish alone (slim/prune.py:296-301 applied to the factors of slim/lora.py:206-209): lora_left_out
+ * [K, rank] = L[:, :rank] * c, lora_right_out [rank, N] = (U[:, :rank])^T * c, c = sqrt(rank) when prescale != 0, else 1. */
+int slim_lora_adapters(const void* U, const void* L, int64_t N, int64_t K, int r8, int rank, int prescale, void* lora_left_out,
+                       void* lora_right_out, void* stream);
 /* The head of add_lora with the Wanda mask before it, slim/prune.py:264-272 + slim/lora.py:139-156, for a per-tensor
  * quantiser (or none) and quantize_first, in one call: s_out [K] = sqrt(scaler_row); mask [N, K] = prune_nm(|W| * s, prune_n,
  * prune_m) when prune_n > 0 (else `mask` is read: a precomputed mask, prune.py:269-271); sf_out = the scale of W (quant_mode

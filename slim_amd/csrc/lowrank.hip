@@ -1178,6 +1178,24 @@ extern "C" int slim_lora_finish(const void* U, const void* L, int64_t N, int64_t
     return SLIM_OK;
 }
 
+// The last step of slim_lora_finish alone (slim/prune.py:296-301 on the factors of slim/lora.py:206-209): lora_left_out
+// [K, rank] = L[:, :rank] * c, lora_right_out [rank, N] = (U[:, :rank])^T * c with c = sqrt(rank) (prescale != 0) or 1, for
+// callers that produce the residual weight themselves (a linear held in shards by several GPUs).
+extern "C" int slim_lora_adapters(const void* U, const void* L, int64_t N, int64_t K, int r8, int rank, int prescale,
+                                  void* lora_left_out, void* lora_right_out, void* stream) {
+    SLIM_REQUIRE(U && L && lora_left_out && lora_right_out, "slim_lora_adapters: null pointer");
+    SLIM_REQUIRE(N > 0 && K > 0 && r8 > 0 && r8 % 8 == 0 && rank > 0 && rank <= r8 && N < (1 << 30) && K < (1 << 30),
+                 "slim_lora_adapters: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const float sq = prescale ? sqrtf((float)rank) : 1.f;
+    scale_cut_kernel<<<(unsigned)ceil_div64(K * rank, 256), 256, 0, st>>>((const bf16_t*)L, K, r8, rank, sq, (bf16_t*)lora_left_out);
+    SLIM_LAUNCH_CHECK();
+    const dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)ceil_div64(rank, 64));
+    scale_transpose_cut_kernel<<<grid, 256, 0, st>>>((const bf16_t*)U, N, r8, rank, sq, (bf16_t*)lora_right_out);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
 // ---- factors of a fit with split-off outlier columns, assembled -----------------------------------------------------------
 // out [rows, r8]: columns < t from `exact` [rows, tp] (each row divided by bf16(s[row]) when s is given, the arithmetic of
 // scale_rows_kernel), columns t .. rank - 1 from the first rank - t columns of `fit` [rows, rf], the rest zero

@@ -691,15 +691,19 @@ def gramfit_check(evals, r, cond_e, scal, info):
     return info
 
 
-def gramfit_project(X, Pt):
-    """X [rows, Dm] (a shard of E or E^T), Pt [l, Dm] -> (Z = X P [rows, l], Zt [l, rows], M32 = Z^T Z fp32 [l, l])."""
+def gramfit_project(X, Pt, M32=None):
+    """X [rows, Dm] (a shard of E or E^T), Pt [l, Dm] -> (Z = X P [rows, l], Zt [l, rows], M32 = Z^T Z fp32 [l, l]; written
+    into the given contiguous tensor when M32 is passed)."""
     X = _chk(X, BF16, "X")
     Pt = _chk(Pt, BF16, "Pt")
     rows, Dm = X.shape
     l = Pt.shape[0]
     Z = torch.empty(rows, l, dtype=BF16, device=X.device)
     Zt = torch.empty(l, rows, dtype=BF16, device=X.device)
-    M32 = torch.empty(l, l, dtype=torch.float32, device=X.device)
+    if M32 is None:
+        M32 = torch.empty(l, l, dtype=torch.float32, device=X.device)
+    elif M32.dtype != torch.float32 or tuple(M32.shape) != (l, l) or not M32.is_contiguous():
+        raise ValueError("M32 must be a contiguous fp32 [l, l] tensor")
     ws = _ws(_lib.query("slim_gramfit_workspace_bytes", rows, l), X.device)
     _lib.call("slim_gramfit_project", _p(X), rows, Dm, l, _p(Pt), _p(Z), _p(Zt), _p(M32), _p(ws), ws.numel(), _stream())
     return Z, Zt, M32
@@ -806,6 +810,20 @@ def lora_assemble(UO, Ct, s, fitU, fitL, t, rank, r8):
     _lib.call("slim_lora_assemble", _p(UO), _p(Ct), _p(s), _p(fitU), _p(fitL), N, K, tp, int(t), rf, int(rank), int(r8), _p(U), _p(Ut),
               _p(L), _stream())
     return U, Ut, L
+
+
+def lora_adapters(U, L, rank, prescale=True):
+    """(lora_left [K, rank], lora_right [rank, N]) from the factors U [N, r8], L [K, r8]: cut to `rank` columns, multiplied
+    by sqrt(rank) when prescale (slim/prune.py:296-301), U transposed (slim_lora_adapters)."""
+    U, L = _chk(U, BF16, "U"), _chk(L, BF16, "L")
+    N, r8 = U.shape
+    K = L.shape[0]
+    if L.shape[1] != r8:
+        raise ValueError("U and L must have the same number of columns")
+    left = torch.empty(K, rank, dtype=BF16, device=U.device)
+    right = torch.empty(rank, N, dtype=BF16, device=U.device)
+    _lib.call("slim_lora_adapters", _p(U), _p(L), N, K, r8, int(rank), int(bool(prescale)), _p(left), _p(right), _stream())
+    return left, right
 
 
 def outlier_basis(Et, cols, t):

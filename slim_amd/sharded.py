@@ -79,6 +79,8 @@ def _t(x):
 
 def _gather_blocks(x, bounds, dim, group=None):
     """x: this rank's block along `dim` of a 2-D tensor (block sizes given by bounds); returns the whole tensor."""
+    if len(bounds) == 1:
+        return x.contiguous()
     sizes = [hi - lo for lo, hi in bounds]
     mx = max(sizes)
     xt = x.contiguous() if dim == 0 else _t(x)
@@ -107,42 +109,57 @@ def _scale(hist, numel, quantizer):
     return ops.absmax_scale(hist, quantizer.num_bits)[1]
 
 
+_aranges = {}
+
+
+def _arange(tp, dev):
+    key = (tp, str(dev))
+    if key not in _aranges:
+        _aranges[key] = torch.arange(tp, dtype=torch.int32, device=dev)
+    return _aranges[key]
+
+
 def _deflate(j, outliers, dev, group):
     """Outlier columns of E (saliency scale far above the median) are represented exactly before the fit, as in
     lora.fit_error_matrix: with Q_O an orthonormal basis of their span, E = Q_O (Q_O^T E) + E'.  The columns are
-    collected from the blocks, the small basis is formed on every rank from identical input (identical result), and every
-    rank deflates its block.  Leaves j.E_s / j.Et_s = the block of E', j.defl_rows = the block's rows of the exact part's
-    factor on the sharded side, j.defl_dm = the whole factor on the other side."""
+    collected from the blocks (as rows of E^T: bf16, every entry from exactly one rank), the small basis is formed on every
+    rank from identical input (identical result, and the basis a single GPU computes), and every rank deflates its block
+    (ops.deflate_apply: E' and its transpose in one pass).  Leaves j.E_s / j.Et_s = the block of E', j.defl_rows = the
+    block's rows of the exact part's factor on the sharded side, j.defl_dm = the whole factor on the other side; the factor
+    that becomes lora_left is left undivided by the saliency scales (ops.lora_assemble divides)."""
     cols, t = outliers
     tp = cols.numel()
-    N, K = j.N, j.K
-    EO = torch.zeros(N, tp, dtype=torch.float32, device=dev)
+    world = len(j.bounds)
     if j.right:
-        EO[j.lo:j.hi] = torch.index_select(j.E_s, 1, cols).float()
+        # rows `cols` of E_s^T [K, rows_s]: this block's part of the outlier columns; the ranks' parts side by side
+        EOt = _gather_blocks(torch.index_select(j.Et_s, 0, cols), j.bounds, 1, group)             # [tp, N]
     else:
-        own = ((cols >= j.lo) & (cols < j.hi)).float()
+        # column blocks: a column lives on one rank, the others contribute zeros
+        own = ((cols >= j.lo) & (cols < j.hi))
         local = (cols - j.lo).clamp(0, j.hi - j.lo - 1)
-        EO.copy_(torch.index_select(j.E_s, 1, local).float() * own.reshape(1, -1))
-    parallel.all_reduce(EO, group)              # every entry comes from exactly one rank
-    # the gathered columns are bf16 values (every entry comes from one rank's block of E): the single-GPU basis routine
-    # on them gives every rank the basis a single GPU computes
-    UO, UOt = ops.outlier_basis(EO.t().contiguous().to(torch.bfloat16), torch.arange(tp, dtype=torch.int32, device=dev), t)
-    j.info_o = torch.zeros(64, dtype=torch.int32, device=dev)
+        EOt = torch.index_select(j.Et_s, 0, local) * own.reshape(-1, 1).to(torch.bfloat16)        # [tp, N]
+        if world > 1:
+            EO32 = EOt.float()
+            parallel.all_reduce(EO32, group)
+            EOt = EO32.to(torch.bfloat16)
+    UO, UOt = ops.outlier_basis(EOt, _arange(tp, dev), t)
+    j.info_o = None            # (the basis routine drops a vanishing pivot's column instead of failing: nothing to report)
     if j.right:
         # C = Q_O^T E [tp, K]: a sum over the row blocks
-        C32 = ops.gemm_nt(UOt[:, j.lo:j.hi].contiguous(), j.Et_s, out_f32=True)[0]
-        parallel.all_reduce(C32, group)
-        Ct = C32.to(torch.bfloat16).t().contiguous()                   # [K, tp]
-        UO_s = UO[j.lo:j.hi].contiguous()
-        j.E_s = ops.lowrank_residual(UO_s, Ct, j.E_s, None)
-        j.defl_rows = UO_s
-        j.defl_dm = ops.scale_rows(Ct.clone(), j.s) if j.s is not None else Ct
+        if world == 1:
+            Ct = ops.outlier_project(j.Et_s, UOt)                      # [K, tp]
+            UO_s = UO
+        else:
+            C32 = ops.gemm_nt(UOt[:, j.lo:j.hi].contiguous(), j.Et_s, out_f32=True)[0]
+            parallel.all_reduce(C32, group)
+            Ct = C32.to(torch.bfloat16).t().contiguous()
+            UO_s = UO[j.lo:j.hi].contiguous()
+        j.E_s, j.Et_s = ops.deflate_apply(j.E_s, UO_s, Ct)
+        j.defl_rows, j.defl_dm = UO_s, Ct
     else:
-        _, C, Ct_s = ops.gemm_nt(UOt, j.Et_s, out_bf16=True, out_t=True)      # [tp, K_s], [K_s, tp]
-        j.E_s = ops.lowrank_residual(UO, Ct_s, j.E_s, None)
-        j.defl_rows = ops.scale_rows(Ct_s.clone(), j.s_s) if j.s_s is not None else Ct_s
-        j.defl_dm = UO
-    j.Et_s = ops.transpose(j.E_s)
+        Ct_s = ops.outlier_project(j.Et_s, UOt)                        # [K_s, tp]
+        j.E_s, j.Et_s = ops.deflate_apply(j.E_s, UO, Ct_s)
+        j.defl_rows, j.defl_dm = Ct_s, UO
 
 
 def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank, slim_lora=True, tile=None, callback=None,
@@ -307,9 +324,8 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         if j.Pt is None:
             j.Pt = ops.transpose(j.P)
         # right: Z_s = E_s P [rows, l];  left: Z_s = E_s^T P [K_s, l]
-        j.Z, _, M = ops.gramfit_project(j.E_s if j.right else j.Et_s, j.Pt)
         k, b = where[idx]
-        Ms[k][b].copy_(M)
+        j.Z = ops.gramfit_project(j.E_s if j.right else j.Et_s, j.Pt, M32=Ms[k][b])[0]
     fan_out(project)
     for k in sizes:
         parallel.all_reduce(Ms[k], group)
@@ -332,9 +348,10 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         members = classes[key]
         # the owner's reports: conditioning against what the spectrum shows, measured spread, where the cut sits
         ops.gramfit_check(torch.stack([jobs[i].evals for i in members]), jobs[members[0]].rf, key[3], scal, info)
-        for b, i in enumerate(members):
-            status[i, 0] = (info[b, :-3].ne(0).any() | jobs[i].tail.ne(0)).to(torch.int32)
-            status[i, 1:] = info[b, -3:].flip(0)
+        bad = info[:, :-3].ne(0).any(1) | torch.stack([jobs[i].tail for i in members]).ne(0)
+        report = torch.cat([bad.to(torch.int32).reshape(-1, 1), info[:, -3:].flip(1)], 1)
+        for b, i in enumerate(members):           # (row by row: an index tensor built from a host list would wait for the GPU)
+            status[i] = report[b]
 
     # ---- phase 4: factors, residual, second histograms (one all-reduce), re-quantisation, gather ---------------------------
     hists.zero_()
@@ -351,22 +368,22 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
             if j.rank_ != r8:
                 rows_full[:, j.rank_:] = 0
                 dm_full[:, j.rank_:] = 0
-        else:
+        elif j.t == 0:
             rows_full = torch.zeros(rows.shape[0], r8, dtype=torch.bfloat16, device=dev)
             dm_full = torch.zeros(j.Dm, r8, dtype=torch.bfloat16, device=dev)
-            if j.t:
-                rows_full[:, :j.t] = j.defl_rows[:, :j.t]
-                dm_full[:, :j.t] = j.defl_dm[:, :j.t]
-            rows_full[:, j.t:j.rank_] = rows[:, :nfit]
-            dm_full[:, j.t:j.rank_] = dm[:, :nfit]
+            rows_full[:, :j.rank_] = rows[:, :nfit]
+            dm_full[:, :j.rank_] = dm[:, :nfit]
+        elif j.right:
+            # U rows = [Q_O rows | fit], lora_left = [C^T / bf16(s) | fit] (one call: the exact part in front, zeros behind)
+            rows_full, _, dm_full = ops.lora_assemble(j.defl_rows, j.defl_dm, j.s, rows, dm, j.t, j.rank_, r8)
+        else:
+            # U = [Q_O | fit], lora_left rows = [C^T rows / bf16(s) | fit]
+            dm_full, _, rows_full = ops.lora_assemble(j.defl_dm, j.defl_rows, j.s_s, dm, rows, j.t, j.rank_, r8)
         j.rows_full, j.dm_full = rows_full, dm_full
         U_s, L_s = (rows_full, dm_full) if j.right else (dm_full, rows_full)
         j.Wn_s = ops.lowrank_residual(U_s, L_s, j.W_s, j.mask_s)                    # lora.py:199-201
         ops.hist_abs(j.Wn_s, hists[idx])
     fan_out(factors)
-    for idx, j in enumerate(jobs):
-        if j.info_o is not None:
-            status[idx, 0] |= j.info_o.ne(0).any().to(torch.int32)
     parallel.all_reduce(hists, group)
     parallel.all_reduce(status, group, op="max")
     mark("factors")
@@ -381,6 +398,10 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         j.W_all = _gather_blocks(j.Wq_s, j.bounds, 0 if j.right else 1, group)
         j.rows_all = _gather_blocks(j.rows_full, j.bounds, 0, group)
 
+    infos = torch.zeros(n, 64, dtype=torch.int32, device=dev)
+    infos[:, 0] = status[:, 0]
+    infos[:, -3:] = status[:, 1:].flip(1)
+
     def attach(idx):
         j = jobs[idx]
         name, lin, wrapped = items[idx]
@@ -389,14 +410,11 @@ def compress_linears_sharded(items, dev, prune_n, prune_m, quantizer, lora_rank,
         sf_out = (j.sf2 if quantizer.slim_quant else j.sf2.to(torch.bfloat16)).reshape(1, 1)
         lin.scaling_factor = sf_out
         lin.lora_rank = torch.tensor(j.rank_)
-        sq = float(j.rank_) ** 0.5
-        lin.lora_left = torch.nn.Parameter(L[:, :j.rank_].contiguous() * sq)
-        lin.lora_right = torch.nn.Parameter(ops.transpose(U)[:j.rank_].contiguous() * sq)
-        info = torch.zeros(64, dtype=torch.int32, device=dev)
-        info[0] = status[idx, 0]
-        info[-3:] = status[idx, 1:].flip(0)
-        lin.lora_fit_info = info
-        j.left, j.right_t, j.info_out, j.sf_out = lin.lora_left.data, lin.lora_right.data, info, sf_out
+        left, right = ops.lora_adapters(U, L, j.rank_, prescale=True)               # prune.py:296-301
+        lin.lora_left = torch.nn.Parameter(left)
+        lin.lora_right = torch.nn.Parameter(right)
+        lin.lora_fit_info = infos[idx]
+        j.left, j.right_t, j.sf_out = left, right, sf_out
     fan_out(attach)
     mark("gather+attach")
     if trace:

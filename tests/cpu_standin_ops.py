@@ -151,9 +151,39 @@ def ritz_split_supported(l, drop_max):
     return False    # (the stand-in Rayleigh-Ritz stage is the exact eigen-decomposition below)
 
 
-def gramfit_project(X, Pt):
+def gramfit_project(X, Pt, M32=None):
     Z = (X.float() @ Pt.float().t()).to(BF16)
-    return Z, Z.t().contiguous(), Z.float().t() @ Z.float()
+    M = Z.float().t() @ Z.float()
+    if M32 is not None:
+        M32.copy_(M)
+        M = M32
+    return Z, Z.t().contiguous(), M
+
+
+def lora_adapters(U, L, rank, prescale=True):
+    c = float(rank) ** 0.5 if prescale else 1.0
+    return (L[:, :rank].float() * c).to(BF16).contiguous(), (U[:, :rank].float() * c).to(BF16).t().contiguous()
+
+
+def outlier_project(Et, UOt):
+    return (Et.float() @ UOt.float().t()).to(BF16)
+
+
+def deflate_apply(E, UO, Ct, out=None):
+    E2 = (E - (UO.float() @ Ct.float().t()).to(BF16)).to(BF16)
+    return E2, E2.t().contiguous()
+
+
+def lora_assemble(UO, Ct, s, fitU, fitL, t, rank, r8):
+    """[exact part | the fit's factors | 0] (slim_lora_assemble)."""
+    N, K = UO.shape[0], fitL.shape[0]
+    U = torch.zeros(N, r8, dtype=BF16)
+    L = torch.zeros(K, r8, dtype=BF16)
+    U[:, :t] = UO[:, :t]
+    L[:, :t] = Ct[:, :t] if s is None else (Ct[:, :t] / s.to(BF16).reshape(-1, 1)).to(BF16)
+    U[:, t:rank] = fitU[:, :rank - t]
+    L[:, t:rank] = fitL[:, :rank - t]
+    return U, U.t().contiguous(), L
 
 
 def tridiagonalize_batched(A):
