@@ -76,13 +76,27 @@ def _run(args):
     if args.ppl:
         test.input_ids = test.input_ids[:, :8 * args.seqlen]
         out["ppl_dense_fp32loss"] = eval_ppl_wikitext(model, test, 1, dev, fp32_loss=True)
+    # passes over (part of) a block's linears: one per block when every fit was sized well, one more for a block that had to
+    # repeat fits (hint of the previous block too low, filter interval too high)
+    import slim_amd.prune as _prune
+    passes = [0]
+    one_pass = _prune.compress_linears_unchecked
+
+    def counted(*a, **k):
+        passes[0] += 1
+        return one_pass(*a, **k)
+    _prune.compress_linears_unchecked = counted
     torch.cuda.synchronize()
     t0 = time.time()
-    P.prune_and_quantize(model, None, bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5,
-                         sparsity_type="2:4", quantize_weight=True, nsamples=args.nsamples, lora_rank=0.1,
-                         slim_lora=True, quantize_lora=True, lora_tile_size=256)
+    try:
+        P.prune_and_quantize(model, None, bitwidth=4, slim_quant=True, prune_method="wanda", sparsity_ratio=0.5,
+                             sparsity_type="2:4", quantize_weight=True, nsamples=args.nsamples, lora_rank=0.1,
+                             slim_lora=True, quantize_lora=True, lora_tile_size=256)
+    finally:
+        _prune.compress_linears_unchecked = one_pass
     torch.cuda.synchronize()
     dt = time.time() - t0
+    out["blocks_with_repeated_fits"] = passes[0] - cfg["num_hidden_layers"]
     P.get_loaders, P.CALIBRATION_BATCH, P.KEEP_ON_DEVICE, P.COMPRESS_STREAMS = saved
     out.update(compress_wallclock_s=round(dt, 2), weight_GBps=round(nbytes / 1e9 / dt, 3),
                peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
