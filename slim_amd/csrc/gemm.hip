@@ -365,6 +365,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
                             if (u < nc) v[u] += g.beta * g.C32[(int64_t)(row0 + r) * g.ldc32 + col + u];
                         }
                         store_row(row0 + r, v);
+                        if (g.mirror32) {          // the finished values, for the transposed copy below
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) T[r * TS + c + u] = v[u];
+                        }
+                    }
+                } else if (ALL_FORMS && g.mirror32) {
+                    for (int r = rt; r < BM && row0 + r < g.M; r += RSTEP) {
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = T[r * TS + c + u] * g.alpha;
+                        store_row(row0 + r, v);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) T[r * TS + c + u] = v[u];
                     }
                 } else {
                     // fully unrolled: all LDS reads are in flight before the first store is built
@@ -381,6 +394,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
         }
     }
     gemm_stamp(g, 5);
+    if (ALL_FORMS && g.mirror32 && !split && row0 != col0) {
+        // symmetric fp32 product: this tile's transpose goes to the tile below the diagonal, which no workgroup computes.
+        // Lanes walk along the tile's rows (the output's columns): 256 contiguous bytes per wave and output row, and the odd
+        // LDS row stride keeps the column-wise reads conflict-free.
+        __syncthreads();
+        for (int idx = t; idx < BM * BN; idx += NT) {
+            const int c = idx / BM, r = idx % BM;
+            if (row0 + r < g.M && col0 + c < g.N) g.C32[(int64_t)(col0 + c) * g.ldc32 + row0 + r] = T[r * TS + c];
+        }
+    }
     if (g.Ct16 && !split) {
         // a wave writes eight rows of C^T (tile columns) at a time, 8 lanes x 16 bytes = 128 contiguous bytes each
         const int lane = t & 63, wave = t >> 6;
@@ -724,7 +747,10 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     const bool sym_shape = g.M == g.N && BM == BN && g.A == g.B && g.lda == g.ldb;
     const bool sym_split = g.splits > 1 && !g.Ct16;
     const bool sym_mirror = g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f;
-    if (g.sym && !(sym_shape && (sym_split || sym_mirror))) g.sym = 0;
+    // ... or, for an fp32 output alone (possibly accumulated into: beta), its fp32 transpose
+    const bool sym_mirror32 = g.splits <= 1 && g.C32 && !g.C16 && !g.Ct16 && !g.Wn && !g.poly_G && batch == 1 && NT == 256;
+    if (g.sym && !(sym_shape && (sym_split || sym_mirror || sym_mirror32))) g.sym = 0;
+    g.mirror32 = g.sym && sym_mirror32 && !sym_split ? 1 : 0;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
@@ -958,6 +984,7 @@ extern "C" int slim_gram_accum(const void* x, int64_t T, int64_t K, int64_t ld, 
         g.beta = first ? beta : 1.f;
         g.C32 = H;
         g.ldc32 = K;
+        g.sym = 1;            // X^T X: the tiles on and above the diagonal, mirrored (H is symmetric on entry: zeros or a previous H)
         int rc = slim_gemm_launch(g, stream);
         if (rc) return rc;
         first = false;
