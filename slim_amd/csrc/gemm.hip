@@ -88,7 +88,41 @@ __device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, const GemmArgs& gi
     // served by L2
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     int tm, tn;
-    if (g.sym) {
+    if (g.sym && g.sym_block > 1) {
+        // tiles on and above the diagonal in square blocks of sym_block x sym_block tiles (block rows, then the tiles of a
+        // block): the run of consecutive tiles that one XCD works on at a time then shares sym_block row panels and
+        // sym_block column panels in its L2, where a row-by-row order shares one row panel and as many column panels as
+        // there are tiles
+        const int S = g.sym_block, nb = (tiles_n + S - 1) / S;
+        int rest = wgid, br = 0, bc = 0;
+        bool found = false;
+        for (br = 0; br < nb && !found; ++br) {
+            const int nr = min(S, tiles_n - br * S);
+            for (bc = br; bc < nb; ++bc) {
+                const int nc = min(S, tiles_n - bc * S);
+                const int cnt = bc == br ? nr * (nr + 1) / 2 : nr * nc;
+                if (rest < cnt) {
+                    found = true;
+                    break;
+                }
+                rest -= cnt;
+            }
+            if (found) break;
+        }
+        const int nc = min(S, tiles_n - bc * S);
+        if (bc == br) {
+            int r = 0;
+            while (rest >= nc - r) {
+                rest -= nc - r;
+                ++r;
+            }
+            tm = br * S + r;
+            tn = bc * S + r + rest;
+        } else {
+            tm = br * S + rest / nc;
+            tn = bc * S + rest % nc;
+        }
+    } else if (g.sym) {
         // tiles on and above the diagonal, row by row: row tm holds tiles_n - tm of them
         tm = 0;
         int rest = wgid;
@@ -695,6 +729,11 @@ static const bool g_tall_tile = [] {
     return !(v && v[0] == '0');
 }();
 
+// SLIM_GEMM_SYM_BLOCK=n (A/B aid): block size of the symmetric products' tile order (0 or 1: row by row)
+static const int g_sym_block = [] {
+    const char* v = getenv("SLIM_GEMM_SYM_BLOCK");
+    return v ? atoi(v) : 8;
+}();
 static int gemm_pick_tile(int family) {
     if (g_tile_override >= 0) return g_tile_override;
     return g_family_tile[family] >= 0 ? g_family_tile[family] : TILE_128x128;
@@ -745,12 +784,14 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     // symmetric products: with split-K the reduction mirrors the lower tiles; without it the workgroups of the upper
     // tiles write their tile and its transpose, which the caller asks for by aiming C^T at C itself (bf16 outputs only)
     const bool sym_shape = g.M == g.N && BM == BN && g.A == g.B && g.lda == g.ldb;
+    const int tiles_m_early = (g.M + BM - 1) / BM;
     const bool sym_split = g.splits > 1 && !g.Ct16;
     const bool sym_mirror = g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f;
     // ... or, for an fp32 output alone (possibly accumulated into: beta), its fp32 transpose
     const bool sym_mirror32 = g.splits <= 1 && g.C32 && !g.C16 && !g.Ct16 && !g.Wn && !g.poly_G && batch == 1 && NT == 256;
     if (g.sym && !(sym_shape && (sym_split || sym_mirror || sym_mirror32))) g.sym = 0;
     g.mirror32 = g.sym && sym_mirror32 && !sym_split ? 1 : 0;
+    g.sym_block = g.sym && tiles_m_early >= 16 ? g_sym_block : 0;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");

@@ -33,6 +33,7 @@ struct GemmArgs {
     // value is what the lower tile would have produced, since every product of the sum commutes)
     // (without split-K: set Ct16 = C16 and ldct = ldc16; the upper tiles then write themselves and their mirror image)
     int sym = 0;
+    int sym_block = 0;  // set by the launcher: tile order of a symmetric product, see gemm_tile_origin
     int mirror32 = 0;   // set by the launcher: a symmetric product with an fp32 output -- the workgroups of the tiles above the
                         // diagonal also write their tile's transpose into C32 (which must be symmetric on entry when beta != 0)
     // strided batch (gridDim.z problems of identical shape); element strides between consecutive problems
