@@ -135,6 +135,10 @@ int slim_hist_abs_bf16(const void* W_bf16, int64_t numel, uint32_t* hist, int ac
 int64_t slim_quant_search_workspace_bytes(int num_bins);
 int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* alpha_out, int32_t* idx_out,
                       float* sf_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Self-check of the exact remainder the scale search's floor division (quantization.py:25, `//` on fp32 tensors) is built
+ * on: out_fast[i] = the library's own remainder of a[i] / b[i] (a >= 0, b > 0), out_ref[i] = fmodf(a[i], b[i]); the two
+ * must be equal bit for bit (tests/test_hip_kernels.py). */
+int slim_fmod_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream);
 /* slim_quant_search for callers that cannot allocate or bring a workspace (HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is a 240 128-byte array inside the
  * library's code object (one copy per GPU, held until the process ends), enough for num_bins <= 20000; more bins return

@@ -168,10 +168,31 @@ __global__ __launch_bounds__(1024) void rebin_kernel(const uint32_t* __restrict_
     }
 }
 
+// fmodf(a, b) for finite a >= 0, b > 0 whose quotient is below 2^23, without the library routine's loop: with n =
+// trunc(a / b) the remainder a - n b is a multiple of the smaller operand's unit and below b, hence representable, so one
+// fused multiply-add returns it exactly.  The division is rounded to nearest and can only overshoot an integer, never
+// fall below one (integers of that size are representable), so n from floorf(a / b) is at most one too large, which shows as
+// a negative remainder.  Quotients of 2^23 and more (never met in the scale search, whose quotients stay below 2^num_bits
+// for bins under the candidate) take the library routine.
+__device__ __forceinline__ float fmod_pos_f32(float a, float b) {
+    const float qf = a / b;
+    if (!(qf < 8388608.f)) return fmodf(a, b);
+    float n = floorf(qf);
+    float r = __builtin_fmaf(-n, b, a);
+    if (r < 0.f) {
+        n -= 1.f;
+        r = __builtin_fmaf(-n, b, a);
+    } else if (r >= b) {            // (cannot happen with a correctly rounded division; kept as a guard)
+        n += 1.f;
+        r = __builtin_fmaf(-n, b, a);
+    }
+    return r;
+}
+
 // floor division of non-negative fp32 values as the reference's `//` computes it
 // (fmod-based, with the half-way correction), b > 0.
 __device__ __forceinline__ float floor_div_f32(float a, float b) {
-    const float mod = fmodf(a, b);
+    const float mod = fmod_pos_f32(a, b);
     float div = (a - mod) / b;
     if (mod != 0.f && mod < 0.f) div -= 1.f;
     if (div == 0.f) return 0.f;
@@ -233,7 +254,9 @@ __global__ __launch_bounds__(1024) void search_coarse_kernel(float* ws_base, int
 }
 
 // fine scan of [indices[max(tp-1,0)], indices[min(tp+1,10)]), block b evaluates start + b (thousands of workgroups:
-// bound by throughput, 256 threads each)
+// bound by arithmetic, 256 threads each -- about 27 lane-cycles per (candidate, bin) pair, two correctly rounded divisions
+// among them.  Four candidates per workgroup sharing the fetches of the bins, and the fetches batched eight deep, both
+// measured slower: 77 against 64 us)
 __global__ __launch_bounds__(256) void search_fine_kernel(float* ws_base, int bins, int q) {
     __shared__ double red[8];
     SearchWs ws = search_ws(ws_base, bins);
@@ -296,6 +319,22 @@ __global__ __launch_bounds__(1024) void search_argmin_kernel(const float* ws_bas
         // `max_q / abs_max` with a tensor divisor evaluates as reciprocal(abs_max) * max_q (two roundings)
         if (sf_out) sf_out[0] = (1.0f / alpha) * (float)((1 << (num_bits - 1)) - 1);
     }
+}
+
+// Self-check of fmod_pos_f32 (the scale search's floor division stands on it): out_fast[i] = fmod_pos_f32(a[i], b[i]),
+// out_ref[i] = fmodf(a[i], b[i]).  No counterpart in the reference.
+__global__ void fmod_probe_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ out_fast,
+                                  float* __restrict__ out_ref) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_fast[i] = fmod_pos_f32(a[i], b[i]);
+    out_ref[i] = fmodf(a[i], b[i]);
+}
+extern "C" int slim_fmod_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream) {
+    SLIM_REQUIRE(a && b && out_fast && out_ref && n > 0, "slim_fmod_probe_f32: bad arguments");
+    fmod_probe_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out_fast, out_ref);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
 }
 
 // the four launches of the search on a workspace of slim_quant_search_workspace_bytes(num_bins) bytes

@@ -176,6 +176,14 @@ def quant_search(hist, num_bins, num_bits):
     return out[0], idx[0], out[1], ws
 
 
+def fmod_probe(a, b):
+    """(the library's exact remainder of a / b, fmodf(a, b)) element-wise for fp32 a >= 0, b > 0 (slim_fmod_probe_f32)."""
+    a, b = _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    fast, ref = torch.empty_like(a), torch.empty_like(a)
+    _lib.call("slim_fmod_probe_f32", _p(a), _p(b), a.numel(), _p(fast), _p(ref), _stream())
+    return fast, ref
+
+
 def absmax_scale(hist, num_bits):
     out = torch.empty(2, dtype=torch.float32, device=hist.device)
     _lib.call("slim_absmax_scale", _p(hist), num_bits, _p(out), _p(out[1:]), _stream())

@@ -566,3 +566,34 @@ def test_outlier_stats_match_torch(ops):
             if vals[2 + a] == vals[3 + a]:
                 assert idx[a] < idx[a + 1]
         assert bool((vals[2 + k:] == 0).all())
+
+
+def test_exact_remainder_equals_fmodf(ops):
+    """The scale search's floor division (`//` on fp32 tensors, slim/quantization/quantization.py:25) is built on an exact
+    remainder computed with one fused multiply-add instead of the library's fmodf loop: bit-identical on the operands the
+    search meets (bin centres over a fraction of a candidate), on random pairs over 40 binades, on exact multiples and on
+    neighbours of multiples."""
+    g = torch.Generator().manual_seed(12)
+    n = 1 << 20
+    # the search's operands: v in [0, alpha), step = alpha / 2^q
+    alpha = torch.rand(n, generator=g) * 0.3 + 1e-3
+    v = torch.rand(n, generator=g) * alpha
+    cases = [(v, alpha / 16.0), (v, alpha / 256.0), (v, alpha / 4.0)]
+    # wide dynamic range
+    a = torch.exp((torch.rand(n, generator=g) - 0.5) * 28.0)
+    b = torch.exp((torch.rand(n, generator=g) - 0.5) * 28.0)
+    cases.append((a, b))
+    # exact multiples and their neighbours
+    k = torch.randint(0, 1 << 16, (n,), generator=g).float()
+    bb = torch.rand(n, generator=g) + 0.5
+    prod = k * bb
+    cases += [(prod, bb), (torch.nextafter(prod, torch.full_like(prod, 1e30)), bb),
+              (torch.nextafter(prod, torch.zeros_like(prod)), bb), (torch.zeros(n), bb), (bb, bb)]
+    # quotients of 2^23 and beyond take the library routine
+    cases.append((torch.full((n,), 3.0e9) * (torch.rand(n, generator=g) + 0.5), torch.rand(n, generator=g) + 0.5))
+    for a, b in cases:
+        fast, ref = ops.fmod_probe(g2d(a.contiguous()), g2d(b.contiguous()))
+        assert torch.equal(fast.view(torch.int32), ref.view(torch.int32))
+        # and both equal the exact remainder computed in double (representable, see the kernel's comment)
+        exact = torch.fmod(a.double(), b.double()).float()
+        assert torch.equal(ref.cpu(), exact)
