@@ -4,6 +4,8 @@ PyTorch is used for device memory and streams only: every function allocates its
 with torch, passes raw device pointers and the current HIP stream to libslim_hip.so, and
 returns torch tensors.  Inputs must live on a ROCm device; nothing here computes on the CPU.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -512,7 +514,7 @@ def eigh_tail(d, e, Q, vecs, top):
 
 
 # rounds of the Chebyshev-filtered iteration of ritz_split (degrees of the polynomial per round)
-RITZ_SPLIT_DEGREES = (8, 12, 20)
+RITZ_SPLIT_DEGREES = tuple(int(x) for x in os.environ.get("SLIM_RITZ_SPLIT_DEGREES", "8,12,20").split(","))
 
 
 def ritz_split_supported(l, drop_max):
