@@ -283,7 +283,9 @@ def main():
             packed[i] = ops.pack24(lins[i].weight.data, lins[i].scaling_factor, check=False)
         if world > 1:
             # exchange step: every rank receives the compressed linears it does not own -- the weight in the packed form made
-            # above (0.375 byte per element), expanded by the receiver -- and the adapters
+            # above (0.375 byte per element), expanded by the receiver -- and the adapters; everything an owner sends goes out
+            # as one broadcast
+            outgoing, received = {}, []
             for i, (_, n, k, _) in enumerate(LLAMA2_7B_BLOCK):
                 lin = lins[i]
                 r = 512 if min(n, k) >= 4096 else 256
@@ -294,12 +296,14 @@ def main():
                     lin.scaling_factor = torch.empty(1, 1, dtype=torch.float32, device=dev)
                     lin.lora_left = torch.nn.Parameter(torch.empty(k, r, dtype=torch.bfloat16, device=dev))
                     lin.lora_right = torch.nn.Parameter(torch.empty(r, n, dtype=torch.bfloat16, device=dev))
+                    received.append((lin, vals, meta, n, k))
                 else:
                     vals, meta, _ = packed[i]
-                for t in (vals, meta, lin.scaling_factor, lin.lora_left.data, lin.lora_right.data):
-                    parallel.broadcast(t, owner[i])          # RCCL broadcast (host-staged only under a gloo rehearsal)
-                if owner[i] != rank:
-                    lin.weight.data = ops.unpack24(vals, meta, lin.scaling_factor.reshape(1), n, k)
+                outgoing.setdefault(owner[i], []).extend([vals, meta, lin.scaling_factor, lin.lora_left.data, lin.lora_right.data])
+            for src in sorted(outgoing):
+                parallel.broadcast_coalesced(outgoing[src], src)       # RCCL broadcast (host-staged only under a gloo rehearsal)
+            for lin, vals, meta, n, k in received:
+                lin.weight.data = ops.unpack24(vals, meta, lin.scaling_factor.reshape(1), n, k)
 
     def step_rows(n_streams=None):
         # statistics: every rank sums its share of the samples, the per-sample sums are gathered into sample order and

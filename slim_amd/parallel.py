@@ -48,6 +48,31 @@ def broadcast(t, src, group=None):
     return t
 
 
+def broadcast_coalesced(tensors, src, group=None):
+    """One broadcast for several tensors of any dtypes and shapes (identical lists on every rank; the receivers' tensors
+    are overwritten).  The owner copies them into one byte buffer, the receivers copy them out: a compressed decoder block
+    is some thirty-five tensors, and a collective costs tens of microseconds before its first byte moves, which is what
+    a step of a few milliseconds notices; the extra copies run at HBM speed."""
+    tensors = [t for t in tensors if t is not None]
+    if _alone(group) or not tensors:
+        return
+    offs, total = [], 0
+    for t in tensors:
+        offs.append(total)
+        total += -(-t.numel() * t.element_size() // 16) * 16
+    flat = torch.empty(total, dtype=torch.uint8, device=tensors[0].device)
+    mine = dist.get_rank(group) == src
+    if mine:
+        for t, o in zip(tensors, offs):
+            n = t.numel() * t.element_size()
+            flat[o:o + n].copy_(t.contiguous().reshape(-1).view(torch.uint8))
+    broadcast(flat, src, group)
+    if not mine:
+        for t, o in zip(tensors, offs):
+            n = t.numel() * t.element_size()
+            t.copy_(flat[o:o + n].view(t.dtype).reshape(t.shape))
+
+
 def _op(op):
     return {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op]
 
@@ -106,7 +131,7 @@ def packable(N, K, prune_n, prune_m, bits):
 
 
 def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True, scale_dtype=torch.float32,
-                    has_left_mask=False, packed=False):
+                    has_left_mask=False, packed=False, defer=None):
     """Broadcast one compressed linear from its owner.  shapes = (N, K, r).  Non-owners allocate receive
     buffers; afterwards every rank holds weight.data [N, K], lora_left [K, r], lora_right [r, N],
     scaling_factor (1, 1) in scale_dtype (fp32 under SLiM-Quant, bf16 under abs-max: what the owner's quantiser
@@ -114,7 +139,10 @@ def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True
     packed=True (a 2:4 sparse 4-bit weight, see packable): the weight travels in its packed form -- codes and positions,
     0.375 byte per element instead of 2 -- and the receivers expand it; pack and unpack are exact inverses on such
     weights up to the sign of zeros (a level that rounds to -0 arrives as +0), so the receivers' tensor equals the
-    owner's under ==."""
+    owner's under ==.
+    defer (a list, optional): the tensors are appended to it instead of being broadcast, and the function returns the
+    callable that completes the linear once the caller has exchanged them (broadcast_coalesced: one collective for all
+    linears of an owner)."""
     from . import ops
     N, K, r = shapes
     dt = lin.weight.dtype
@@ -145,15 +173,22 @@ def exchange_linear(lin, owner, rank, shapes, device, group=None, has_scale=True
         tensors += [vals, meta]
     else:
         tensors.append(lin.weight.data)
+    m8 = lin.lora_left_mask.to(torch.uint8) if has_left_mask else None    # bool has no broadcast support in every backend
+    if m8 is not None:
+        tensors.append(m8)
+
+    def complete():
+        if packed and owner != rank:
+            lin.weight.data = ops.unpack24(vals, meta, lin.scaling_factor.float().reshape(1), N, K)
+        if m8 is not None:
+            lin.lora_left_mask = m8.bool()
+        return lin
+    if defer is not None:
+        defer.extend(tensors)
+        return complete
     for t in tensors:
         broadcast(t, owner, group)
-    if packed and owner != rank:
-        lin.weight.data = ops.unpack24(vals, meta, lin.scaling_factor.float().reshape(1), N, K)
-    if has_left_mask:
-        m8 = lin.lora_left_mask.to(torch.uint8)         # bool has no reduction/broadcast support in every backend
-        broadcast(m8, owner, group)
-        lin.lora_left_mask = m8.bool()
-    return lin
+    return complete()
 
 
 def gather_sample_stats(local_sumsq, group=None):

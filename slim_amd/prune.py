@@ -654,24 +654,33 @@ def _exchange_block(names, subset, owner, rank, dev, lora_rank, tiled_rank, lora
     """Every rank receives the compressed form of the linears it does not own (weight, adapters, scale, mask of pruned
     adapters) and gives them the attributes and the hook the owner's copy has."""
     from .lora import lora_rank as rank_of
+    # everything an owner has to send goes out as ONE broadcast (parallel.broadcast_coalesced)
+    outgoing = {}            # owner -> tensors
+    completions = []
     for j, n in enumerate(names):
         lin = subset[n]
         N, K = lin.weight.shape
+        bucket = outgoing.setdefault(owner[j], [])
         if lora_rank > 0. and separate_lora:
             r = min(rank_of((N, K), lora_rank, lora_tile_size if tiled_rank else None), min(N, K))
             mine = owner[j] == rank
             # a 2:4 sparse 4-bit weight travels packed (0.375 instead of 2 bytes per element), recipe = (n, m, bits)
-            parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale, scale_dtype=scale_dtype,
-                                     has_left_mask=prune_lora, packed=has_scale and parallel.packable(N, K, *recipe))
+            completions.append(parallel.exchange_linear(lin, owner[j], rank, (N, K, r), dev, has_scale=has_scale,
+                                                        scale_dtype=scale_dtype, has_left_mask=prune_lora,
+                                                        packed=has_scale and parallel.packable(N, K, *recipe), defer=bucket))
             if not mine:
                 lin.lora_rank = torch.tensor(r)
                 lin.register_forward_hook(add_lora_hook)
         else:
-            parallel.broadcast(lin.weight.data, owner[j])
+            bucket.append(lin.weight.data)
             if has_scale:
                 if owner[j] != rank:
                     lin.scaling_factor = torch.empty(1, 1, dtype=scale_dtype, device=dev)
-                parallel.broadcast(lin.scaling_factor, owner[j])
+                bucket.append(lin.scaling_factor)
+    for src in sorted(outgoing):
+        parallel.broadcast_coalesced(outgoing[src], src)
+    for complete in completions:
+        complete()
     # the owners' packing status words, read with one synchronisation
     # the owners' packing status words, one per linear (0 where nothing was packed), combined over the ranks so that every
     # rank raises together: the receivers have unpacked what the owner sent and would otherwise run on into the next

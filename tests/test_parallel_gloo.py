@@ -56,6 +56,31 @@ def _worker(rank, world, port, q):
         ok &= torch.equal(lins[i].lora_left.data, torch.randn(k, r, generator=g).to(torch.bfloat16))
         ok &= torch.equal(lins[i].lora_right.data, torch.randn(r, n, generator=g).to(torch.bfloat16))
         ok &= float(lins[i].scaling_factor) == 100.0 + i
+    # the same exchange with every owner's tensors in ONE broadcast (deferred form + broadcast_coalesced): mixed dtypes,
+    # byte counts that are no multiple of the buffer's alignment (the 4-byte scales), identical results
+    from slim_amd.parallel import broadcast_coalesced
+    outgoing, completions, lins2 = {}, [], []
+    for i, (n, k, r) in enumerate(shapes):
+        lin = torch.nn.Linear(k, n, bias=False).to(torch.bfloat16)
+        if owner[i] == rank:
+            for name in ("lora_left", "lora_right", "scaling_factor"):
+                setattr(lin, name, getattr(lins[i], name))
+            lin.weight.data = lins[i].weight.data.clone()
+        if owner[i] == rank:
+            lin.lora_left_mask = torch.arange(k * r).reshape(k, r) % (i + 2) == 0
+        completions.append(exchange_linear(lin, owner[i], rank, (n, k, r), "cpu", has_left_mask=True,
+                                           defer=outgoing.setdefault(owner[i], [])))
+        lins2.append(lin)
+    for src in sorted(outgoing):
+        broadcast_coalesced(outgoing[src], src)
+    for complete in completions:
+        complete()
+    for i in range(len(shapes)):
+        for name in ("lora_left", "lora_right", "scaling_factor"):
+            ok &= torch.equal(getattr(lins2[i], name).data, getattr(lins[i], name).data)
+        ok &= torch.equal(lins2[i].weight.data, lins[i].weight.data)
+        n, k, r = shapes[i]
+        ok &= torch.equal(lins2[i].lora_left_mask, torch.arange(k * r).reshape(k, r) % (i + 2) == 0)
     # sample-ordered statistics gather
     local = torch.full((2, 8), float(rank)) + torch.arange(2).reshape(2, 1)
     allst = gather_sample_stats(local)
