@@ -22,15 +22,17 @@
 // is (32 FM) x (32 FN).  The big tile has the best reuse; the small ones exist because the products of the fit are
 // small (a few hundred tiles at most) and each workgroup's K-loop is bound by load latency: more, smaller workgroups
 // keep more loads in flight per CU and fill the 256 CUs.
-// Variants 0-3 stage tiles through registers (one K-step ahead, padded LDS rows); 4+ use LDS-DMA, several stages deep.
+// Variants 0-4 stage tiles through registers (one K-step ahead, padded LDS rows); the DMA variants deliver them by LDS-DMA,
+// several K-steps ahead (gemm_nt_dma_kernel).
 // TILE_288x128 (512 threads, 2 x 4 waves of 144 x 32): for products whose M is the subspace dimension of the fit (576 = 2 x 288,
 // 1152 = 4 x 288): no padded rows, and the four (l x Dm) products of a chain are 256 tiles -- one per CU, two waves per SIMD --
 // instead of 640 tiles of 128 x 128 on 512 workgroup slots
-enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, TILE_288x128, TILE_COUNT };
-static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 288};
-static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128};
-static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64};
-static const int kTileThreads[TILE_COUNT] = {256, 256, 256, 256, 512};
+enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, TILE_288x128, TILE_DMA_288x128, TILE_DMA_128x128, TILE_DMA_256x128, TILE_COUNT };
+static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 288, 288, 128, 256};
+static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 128, 128, 128};
+static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64};
+static const int kTileThreads[TILE_COUNT] = {256, 256, 256, 256, 512, 512, 256, 512};
+static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 0, 3, 4, 3};       // LDS-DMA stages (0: register staging, two buffers)
 
 // BKT elements of the reduction per tile row: BKT / 8 threads cover a row, NT / (BKT / 8) rows per pass of the NT threads; the
 // last pass may cover fewer rows than that (288-row tiles with 512 threads)
@@ -179,12 +181,12 @@ __device__ __forceinline__ void gemm_stamp(const GemmArgs& g, int slot) {
 // fit's short products.  So the tile goes through LDS (free once the K-loop is done) as fp32 [BM][BN + 1] and leaves
 // in whole rows: 16-byte stores along N for C / the split-K slab / the residual, 16-byte stores along M for C^T.
 // The odd row stride keeps both the row-wise and the column-wise LDS reads conflict-free.
-template <int FM, int FN, int WM, int WN>
+template <int FM, int FN, int WM, int WN, bool ALL_FORMS = WM * WN == 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM][FN], float* T, int row0, int col0, int wr,
                                               int wc, int fr, int fq) {
     constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN, TS = BN + 1, NT = 64 * WM * WN;
-    // the eight-wave tall tile is launched for plain bf16 outputs only: the other output forms are compiled out of it
-    constexpr bool ALL_FORMS = NT == 256;
+    // (ALL_FORMS false: the eight-wave tall tiles are launched for plain bf16 outputs only, the other output forms are
+    // compiled out of them)
     __syncthreads();                 // every wave is done with the operand tiles
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -545,6 +547,129 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs gi
     gemm_stamp(g, 3);
 }
 
+// The same product with the operand tiles delivered by LDS-DMA (global_load_lds, 16 bytes per lane), STAGES - 1 K-steps
+// ahead of the matrix instructions.  The products of the fit are a few hundred tiles at most -- one or two workgroups
+// per CU, nothing else resident to hide a K-step's trip to memory -- and with register staging (one step ahead) a K-step
+// costs that trip, 2.5-3.5 times what its matrix instructions take.  The DMA needs no staging registers, so the depth
+// is bounded by LDS alone.
+// LDS image of a stage: the BM rows of A then the BN rows of B, 128 bytes (64 reduction elements) per row, no padding (a
+// wave-instruction of the DMA writes 64 x 16 contiguous bytes: 8 rows); the 16-byte piece c of row r is stored at
+// position c ^ (r & 7), applied on the SOURCE side (lane (r, p) of a piece fetches column p ^ r), which makes the
+// fragment reads (16 rows x one 16-byte column per quarter wave) conflict-free.
+// Ordering: a wave waits for its own DMAs of a stage by count (vmcnt), then the workgroup barrier makes every wave's
+// visible; the stage freed by the previous K-step is refilled after that same barrier.  Needs Kd % 64 == 0.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int FAMILY, int FM, int FN, int WM, int WN, int STAGES, bool ALL_FORMS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArgs gin) {
+    constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN, NW = WM * WN;
+    constexpr int PIECES = (BM + BN) / 8;               // 1 KiB pieces (8 rows) of a stage
+    constexpr int PPW = (PIECES + NW - 1) / NW;         // per wave; the last wave(s) repeat the final piece (same bytes, same place)
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(STAGES >= 2 && (STAGES - 1) * PPW < 64, "the load counter has six bits");
+    GemmArgs g = gin;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    char* const lds = (char*)smem;
+
+    int row0, col0;
+    gemm_tile_origin<BM, BN>(g, gin, row0, col0);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gemm_stamp(g, 0);
+    const int nk_total = g.Kd / BK;
+    const int kt0 = g.splits > 1 ? (int)blockIdx.y * g.ksteps_per_split : 0;
+    const int nk = g.splits > 1 ? min(g.ksteps_per_split, nk_total - kt0) : nk_total;
+
+    // this lane's sources: row (lane / 8) of each of the wave's pieces, 16-byte column (lane % 8) ^ (lane / 8)
+    const bf16_t* src[PPW];
+    int dst[PPW];
+    {
+        const int pr = lane >> 3, pc = (lane & 7) ^ pr;
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int q = min(s * NW + wave, PIECES - 1);
+            const int R = q * 8 + pr;
+            if (R < BM) src[s] = g.A + (int64_t)min(row0 + R, g.M - 1) * g.lda + (int64_t)kt0 * BK + pc * 8;
+            else src[s] = g.B + (int64_t)min(col0 + R - BM, g.N - 1) * g.ldb + (int64_t)kt0 * BK + pc * 8;
+            dst[s] = q * 1024;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[s] + (int64_t)kt * BK), (lds_ptr_t)(lds + buf * STAGE_BYTES + dst[s]), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue(st, st);
+    gemm_stamp(g, 1);
+
+    // fragment addresses: row (.. + fr), 16-byte column (ks * 4 + fq) ^ (fr & 7); the second 32-deep half flips bit 2
+    const int x0 = (fq ^ (fr & 7)) * 16;
+    const int a_off = (wr * 16 * FM + fr) * 128, b_off = (BM + wc * 16 * FN + fr) * 128;
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most the STAGES - 2 younger ones are outstanding
+        if (kt + STAGES - 2 < nk) wait_vmcnt<(STAGES - 2) * PPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // every wave is past the previous K-step's fragment reads: its buffer takes stage kt + STAGES - 1
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, buf == 0 ? STAGES - 1 : buf - 1);
+        const char* a_base = lds + buf * STAGE_BYTES + a_off;
+        const char* b_base = lds + buf * STAGE_BYTES + b_off;
+        // the first 32-deep half's fragments are requested together, the second half's while the first half's products run
+        // (left alone the compiler sinks every read to its first use: an LDS round trip per pair of products)
+        bf16x8 af[2][FM], bfr[2][FN];
+        auto fetch = [&](int ks) {
+            const int x = ks == 0 ? x0 : (x0 ^ 64);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[ks][j] = *(const bf16x8*)(b_base + j * 16 * 128 + x);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[ks][i] = *(const bf16x8*)(a_base + i * 16 * 128 + x);
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+        // the second half's reads go between the first half's products, one per row of fragments
+        __builtin_amdgcn_sched_group_barrier(0x100, FN, 0);          // (B's fragments first)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+    gemm_stamp(g, 2);
+    gemm_epilogue<FM, FN, WM, WN, ALL_FORMS>(g, acc, (float*)smem, row0, col0, wr, wc, fr, fq);
+    gemm_stamp(g, 3);
+}
+
 // C32 / C16 <- alpha * sum over slices of slab[z] (+ beta * C32), slices added in index order.  One 64 x 64 tile per
 // workgroup, read as 16-byte pieces of every slice.  Symmetric products fill only the 128 x 128 tiles on and above the
 // diagonal: the workgroups of the tiles below it leave at once, those above it write their tile and, through LDS, its
@@ -698,6 +823,9 @@ static gemm_kernel_t gemm_kernel_of(int tile) {
         case TILE_64x128: return gemm_nt_kernel<FAMILY, 2, 4>;
         case TILE_64x64: return gemm_nt_kernel<FAMILY, 2, 2>;
         case TILE_288x128: return gemm_nt_kernel<FAMILY, 9, 2, 64, 2, 4>;
+        case TILE_DMA_288x128: return gemm_nt_dma_kernel<FAMILY, 9, 2, 2, 4, 3, false>;
+        case TILE_DMA_128x128: return gemm_nt_dma_kernel<FAMILY, 4, 4, 2, 2, 4, true>;
+        case TILE_DMA_256x128: return gemm_nt_dma_kernel<FAMILY, 4, 4, 4, 2, 3, true>;
         default: return gemm_nt_kernel<FAMILY, 4, 4>;
     }
 }
@@ -723,6 +851,22 @@ extern "C" void slim_gemm_set_family_tile(int family, int tile) {
     if (family >= 0 && family < FAM_COUNT) g_family_tile[family] = (tile >= 0 && tile < TILE_COUNT) ? tile : -1;
 }
 
+// SLIM_GEMM_FAMILY_TILES="family:tile,..." (a tuning aid): slim_gemm_set_family_tile from the environment
+static const bool g_family_tiles_env = [] {
+    const char* v = getenv("SLIM_GEMM_FAMILY_TILES");
+    while (v && *v) {
+        char* end = nullptr;
+        const long fam = strtol(v, &end, 10);
+        if (end == v || *end != ':') break;
+        v = end + 1;
+        const long tile = strtol(v, &end, 10);
+        if (end == v) break;
+        slim_gemm_set_family_tile((int)fam, (int)tile);
+        v = *end == ',' ? end + 1 : end;
+    }
+    return true;
+}();
+
 // SLIM_GEMM_TALL_TILE=0: the 288 x 128 tile is never chosen (A/B aid)
 static const bool g_tall_tile = [] {
     const char* v = getenv("SLIM_GEMM_TALL_TILE");
@@ -733,6 +877,10 @@ static const bool g_tall_tile = [] {
 static const int g_sym_block = [] {
     const char* v = getenv("SLIM_GEMM_SYM_BLOCK");
     return v ? atoi(v) : 8;
+}();
+static const bool g_dma_tiles = [] {
+    const char* v = getenv("SLIM_GEMM_DMA");
+    return !(v && v[0] == '0');
 }();
 static int gemm_pick_tile(int family) {
     if (g_tile_override >= 0) return g_tile_override;
@@ -779,7 +927,11 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     // the projection, l = 576 or 1152 (bf16 outputs, no split-K, no residual / polynomial epilogue)
     const bool tall_ok = g_tile_override < 0 && g_family_tile[fam] < 0 && g_tall_tile && fam == FAM_SKETCH && g.M > 128 && g.M <= 1536 &&
                          g.splits <= 1 && !g.C32 && !g.Wn && !g.poly_G && !g.sym && g.beta == 0.f;
-    if (tall_ok && (288 - g.M % 288) % 288 <= (128 - g.M % 128) % 128) tile = TILE_288x128;
+    // ... fed by LDS-DMA when the reduction is whole 64-deep steps (SLIM_GEMM_DMA=0: register staging everywhere, an A/B aid)
+    if (tall_ok && (288 - g.M % 288) % 288 <= (128 - g.M % 128) % 128) tile = g_dma_tiles && g.Kd % 64 == 0 ? TILE_DMA_288x128 : TILE_288x128;
+    // (a forced DMA tile falls back where its conditions do not hold: whole 64-deep K-steps; plain bf16 outputs for 288 x 128)
+    if (kTileStages[tile] > 0 && g.Kd % 64 != 0) tile = TILE_128x128;
+    if (tile == TILE_DMA_288x128 && (g.splits > 1 || g.C32 || g.Wn || g.poly_G || g.sym || g.beta != 0.f)) tile = TILE_DMA_128x128;
     const int BM = kTileM[tile], BN = kTileN[tile], NT = kTileThreads[tile];
     // symmetric products: with split-K the reduction mirrors the lower tiles; without it the workgroups of the upper
     // tiles write their tile and its transpose, which the caller asks for by aiming C^T at C itself (bf16 outputs only)
@@ -795,7 +947,8 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
-    const int loop_bytes = 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
+    const int loop_bytes = kTileStages[tile] > 0 ? kTileStages[tile] * (BM + BN) * 128
+                                                 : 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
     const int epilogue_bytes = BM * (BN + 1) * (int)sizeof(float);       // the output tile staged as fp32
     const int lds_bytes = loop_bytes > epilogue_bytes ? loop_bytes : epilogue_bytes;
     static const char* const names[FAM_COUNT] = {"gemm_nt_gram", "gemm_nt_small", "gemm_nt_apply", "gemm_nt_sketch",

@@ -81,3 +81,35 @@ def test_tall_tile_equals_square_tile(M, N, Kd):
     assert torch.equal(Ct, C16.t())
     ref = A.double() @ Bt.double().t()
     assert (C16.double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("variant", [5, 6, 7])
+def test_dma_tiles_equal_square_tile(variant):
+    """The tiles fed by LDS-DMA several K-steps ahead (288 x 128, 128 x 128, 256 x 128) against the register-staged 128 x 128
+    tile: the same fp32 sums in the same order, so identical outputs in every form -- full and ragged shapes, reductions
+    shorter than the pipeline is deep, split-K; a reduction that is no multiple of 64 falls back to the register-staged tile."""
+    from slim_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(variant)
+    for M, N, Kd in [(576, 4096, 4096), (576, 2056, 1600), (300, 1000, 64), (128, 128, 128), (1000, 200, 192), (8, 8, 64),
+                     (4096, 576, 576), (640, 640, 520), (512, 512, 2048)]:
+        A = torch.randn(M, Kd, device="cuda", generator=g).to(torch.bfloat16)
+        Bt = torch.randn(N, Kd, device="cuda", generator=g).to(torch.bfloat16)
+        C0 = torch.randn(M, N, device="cuda", generator=g)
+        outs = []
+        for v in (0, variant):
+            _lib.query("slim_gemm_set_tile", v)
+            o = list(ops.gemm_nt(A, Bt, alpha=0.5, out_f32=True, out_bf16=True, out_t=True))
+            o += list(ops.gemm_nt(A, Bt, out_bf16=True, out_t=True))[1:]          # (the form the 288-row tile serves)
+            o.append(ops.gemm_nt(A, Bt, alpha=1.0, beta=2.0, C32=C0.clone(), out_f32=True)[0])
+            if Kd >= 128:
+                o += list(ops.gemm_nt_splitk(A, Bt, splits=2))
+            if M == N:
+                o += list(ops.gemm_nt_splitk(A, A, splits=2)) if Kd >= 128 else []
+                H = C0[:, :M].clone() + C0[:, :M].t()
+                o.append(ops.gemm_nt(A, A, alpha=1.0, beta=0.5, C32=H, out_f32=True)[0])
+            outs.append(o)
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(*outs)):
+            assert torch.equal(a, b), (variant, M, N, Kd, k)
+        ref = 0.5 * (A.double() @ Bt.double().t())
+        assert (outs[1][0].double() - ref).abs().max().item() <= 1e-5 * Kd ** 0.5 * max(1.0, ref.abs().max().item())
