@@ -691,9 +691,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int64_t n = (int64_t)M * N;
     const int tx = (t & 15) * 4, ty = t >> 4;
     const bool vec = (N & 3) == 0 && ((uintptr_t)slab & 15) == 0;
+    // (the four rows of a thread are fetched slice by slice together -- four independent 16-byte loads in flight per slice --
+    // and leave as 16- and 8-byte stores)
+    const bool vec_out = (!C32 || ((ldc32 & 3) == 0 && ((uintptr_t)C32 & 15) == 0)) && (!C16 || ((ldc16 & 3) == 0 && ((uintptr_t)C16 & 7) == 0));
+    const int col = col0 + tx;
+    if (vec && vec_out && col + 3 < N && row0 + 63 < M) {
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[i][u] = 0.f;
+        const float* p = slab + (int64_t)(row0 + ty) * N + col;
+        for (int z = 0; z < splits; ++z) {
+            f32x4 q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = *(const f32x4*)(p + (int64_t)z * n + (int64_t)16 * i * N);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[i][u] += q[i][u];
+        }
+        f32x4 old[4];
+        if (C32 && beta != 0.f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) old[i] = *(const f32x4*)(C32 + (int64_t)(row0 + ty + 16 * i) * ldc32 + col);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + 16 * i, row = row0 + r;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[i][u] *= alpha;
+                if (C32 && beta != 0.f) v[i][u] += beta * old[i][u];
+                tile[r][tx + u] = v[i][u];
+            }
+            if (C32) *(f32x4*)(C32 + (int64_t)row * ldc32 + col) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+            if (C16) {
+                bf16_t o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = f32_to_bf16(row == col + u ? v[i][u] - c16_diag : v[i][u]);
+                *(u16x4*)(C16 + (int64_t)row * ldc16 + col) = u16x4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = ty + 16 * i, row = row0 + r, col = col0 + tx;
+        const int r = ty + 16 * i, row = row0 + r;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < M && col < N) {
             const float* p = slab + (int64_t)row * N + col;
@@ -730,6 +773,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int i = 0; i < 4; ++i) {
         const int c = ty + 16 * i, mrow = col0 + c;          // row of the mirrored position
         if (mrow >= N) continue;
+        if (vec_out && row0 + tx + 3 < M && beta == 0.f) {
+            const float v0 = tile[tx][c], v1 = tile[tx + 1][c], v2 = tile[tx + 2][c], v3 = tile[tx + 3][c];
+            if (C32) *(f32x4*)(C32 + (int64_t)mrow * ldc32 + row0 + tx) = f32x4{v0, v1, v2, v3};
+            if (C16) *(u16x4*)(C16 + (int64_t)mrow * ldc16 + row0 + tx) = u16x4{f32_to_bf16(v0), f32_to_bf16(v1), f32_to_bf16(v2), f32_to_bf16(v3)};
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int mcol = row0 + tx + u;
