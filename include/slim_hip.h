@@ -139,6 +139,10 @@ int slim_quant_search(const uint32_t* hist, int num_bins, int num_bits, float* a
  * on: out_fast[i] = the library's own remainder of a[i] / b[i] (a >= 0, b > 0), out_ref[i] = fmodf(a[i], b[i]); the two
  * must be equal bit for bit (tests/test_hip_kernels.py). */
 int slim_fmod_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream);
+/* Self-check of the floor division itself as the search evaluates it (no division, one fused multiply-add): out_fast[i] =
+ * the library's floor(a[i] / b[i]), out_ref[i] = the reference's `//` written out step by step (remainder, subtraction,
+ * division, half-way correction: quantization.py:25 through torch's floor_divide); equal bit for bit. */
+int slim_floordiv_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream);
 /* slim_quant_search for callers that cannot allocate or bring a workspace (HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is a 240 128-byte array inside the
  * library's code object (one copy per GPU, held until the process ends), enough for num_bins <= 20000; more bins return

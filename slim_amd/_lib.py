@@ -86,6 +86,7 @@ PROTOTYPES = {
     "slim_gramfit_workspace_bytes": (i64, [i64, i64]),
     "slim_gramfit_iterate": (i32, [vp, i64, i32, i32, u32, i32, i32, vp, vp, vp, vp, i64, vp]),
     "slim_fmod_probe_f32": (i32, [vp, vp, i64, vp, vp, vp]),
+    "slim_floordiv_probe_f32": (i32, [vp, vp, i64, vp, vp, vp]),
     "slim_lora_adapters": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]),
     "slim_gramfit_batched_workspace_bytes": (i64, [i32, i64, i64]),
     "slim_gramfit_iterate_batched": (i32, [vp, i32, i64, i32, i32, u32, i32, i32, vp, vp, vp, vp, vp, i64, vp]),

@@ -201,6 +201,26 @@ __device__ __forceinline__ float floor_div_f32(float a, float b) {
     return fl;
 }
 
+// The same floor division without either of its two correctly rounded divisions, for finite a >= 0, b > 0 and rb any fp32
+// approximation of 1 / b good to a few units in the last place.  With n = floor(a / b) (of the real quotient) and the exact
+// remainder r = a - n b, the reference's value is n whatever the roundings of its own steps do: a - r is n b rounded once,
+// the quotient by b is n (1 + d) with |d| < 2^-22, i.e. within a quarter of n for n < 2^20, and the final correction
+// (`div - floor(div) > 0.5`) turns a value just below n back into n; n = 0 gives a - r = 0 and the early return.  And n
+// follows from the estimate floor(a rb), which for quotients below 2^20 is off by at most one (absolute error below
+// 2^-2), through one fused multiply-add: a remainder below zero or not below b says which way.  Quotients of 2^20 and
+// more (the search's stay below 2^num_bits) take the literal form: from 2^22 on the reference's own roundings no longer
+// return n.
+// tests/test_hip_kernels.py compares the two on the search's operands and on adversarial ones (slim_floordiv_probe_f32).
+__device__ __forceinline__ float floor_quot_f32(float a, float b, float rb) {
+    const float qf = a * rb;
+    if (!(qf < 1048576.f)) return floor_div_f32(a, b);
+    float n = floorf(qf);
+    const float r = __builtin_fmaf(-n, b, a);
+    if (r < 0.f) n -= 1.f;
+    else if (r >= b) n += 1.f;
+    return n;
+}
+
 // loss of one candidate index, reduced over the workgroup (256 threads); element-wise terms
 // are formed with the reference's fp32 operations, the sum is carried in fp64.
 template <int NT>
@@ -208,11 +228,12 @@ __device__ float candidate_loss(const SearchWs& ws, int bins, int index, int q, 
     const float alpha = ws.val[index];
     const float dx = ws.val[1] - ws.val[0];
     const float step = alpha / (float)(1 << q);
+    const float rstep = 1.0f / step;
     double sq = 0.0, sc = 0.0;
     for (int j = threadIdx.x; j < bins; j += NT) {
         const float v = ws.val[j], p = ws.pdf[j];
         if (j < index) {
-            const float qv = (step == 0.f ? (v / step) : floor_div_f32(v, step)) * step;
+            const float qv = (step == 0.f ? (v / step) : floor_quot_f32(v, step, rstep)) * step;
             const float d = v - qv;
             sq += (double)(p * (d * d));
         } else {
@@ -254,8 +275,8 @@ __global__ __launch_bounds__(1024) void search_coarse_kernel(float* ws_base, int
 }
 
 // fine scan of [indices[max(tp-1,0)], indices[min(tp+1,10)]), block b evaluates start + b (thousands of workgroups:
-// bound by arithmetic, 256 threads each -- about 27 lane-cycles per (candidate, bin) pair, two correctly rounded divisions
-// among them.  Four candidates per workgroup sharing the fetches of the bins, and the fetches batched eight deep, both
+// bound by arithmetic, 256 threads each -- a floor, a fused multiply-add, two comparisons and the squared difference per
+// (candidate, bin) pair; 27 lane-cycles while the floor division still performed its two correctly rounded divisions.  Four candidates per workgroup sharing the fetches of the bins, and the fetches batched eight deep, both
 // measured slower: 77 against 64 us)
 __global__ __launch_bounds__(256) void search_fine_kernel(float* ws_base, int bins, int q) {
     __shared__ double red[8];
@@ -333,6 +354,31 @@ __global__ void fmod_probe_kernel(const float* __restrict__ a, const float* __re
 extern "C" int slim_fmod_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream) {
     SLIM_REQUIRE(a && b && out_fast && out_ref && n > 0, "slim_fmod_probe_f32: bad arguments");
     fmod_probe_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out_fast, out_ref);
+    SLIM_LAUNCH_CHECK();
+    return SLIM_OK;
+}
+
+// Self-check of floor_quot_f32: out_fast[i] = floor_quot_f32(a[i], b[i], 1 / b[i]); out_ref[i] = the reference's floor
+// division written out step by step with the library remainder (fmodf) and two IEEE divisions.
+__global__ void floordiv_probe_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ out_fast,
+                                      float* __restrict__ out_ref) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    out_fast[i] = floor_quot_f32(x, y, 1.0f / y);
+    const float mod = fmodf(x, y);
+    float div = (x - mod) / y;
+    if (mod != 0.f && mod < 0.f) div -= 1.f;
+    float fl = 0.f;
+    if (div != 0.f) {
+        fl = floorf(div);
+        if (div - fl > 0.5f) fl += 1.f;
+    }
+    out_ref[i] = fl;
+}
+extern "C" int slim_floordiv_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream) {
+    SLIM_REQUIRE(a && b && out_fast && out_ref && n > 0, "slim_floordiv_probe_f32: bad arguments");
+    floordiv_probe_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out_fast, out_ref);
     SLIM_LAUNCH_CHECK();
     return SLIM_OK;
 }

@@ -186,6 +186,15 @@ def fmod_probe(a, b):
     return fast, ref
 
 
+def floordiv_probe(a, b):
+    """(the library's floor(a / b) as the scale search evaluates it, the reference's `//` written out step by step)
+    element-wise for fp32 a >= 0, b > 0 (slim_floordiv_probe_f32)."""
+    a, b = _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    fast, ref = torch.empty_like(a), torch.empty_like(a)
+    _lib.call("slim_floordiv_probe_f32", _p(a), _p(b), a.numel(), _p(fast), _p(ref), _stream())
+    return fast, ref
+
+
 def absmax_scale(hist, num_bits):
     out = torch.empty(2, dtype=torch.float32, device=hist.device)
     _lib.call("slim_absmax_scale", _p(hist), num_bits, _p(out), _p(out[1:]), _stream())

@@ -597,3 +597,8 @@ def test_exact_remainder_equals_fmodf(ops):
         # and both equal the exact remainder computed in double (representable, see the kernel's comment)
         exact = torch.fmod(a.double(), b.double()).float()
         assert torch.equal(ref.cpu(), exact)
+        # the floor division built on it, as the search evaluates it (no division at all), against the reference's `//`
+        # written out step by step -- and against torch's own floor_divide on the same fp32 operands
+        fast, ref = ops.floordiv_probe(g2d(a.contiguous()), g2d(b.contiguous()))
+        assert torch.equal(fast.view(torch.int32), ref.view(torch.int32))
+        assert torch.equal(ref.cpu(), torch.floor_divide(a, b))
