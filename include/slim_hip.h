@@ -144,7 +144,7 @@ int slim_fmod_probe_f32(const float* a, const float* b, int64_t n, float* out_fa
  * division, half-way correction: quantization.py:25 through torch's floor_divide); equal bit for bit. */
 int slim_floordiv_probe_f32(const float* a, const float* b, int64_t n, float* out_fast, float* out_ref, void* stream);
 /* slim_quant_search for callers that cannot allocate or bring a workspace (HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is a 240 128-byte array inside the
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is a 408 064-byte array inside the
  * library's code object (one copy per GPU, held until the process ends), enough for num_bins <= 20000; more bins return
  * SLIM_ERR_INVALID.  Calls no hipMalloc / hipFree.  The first call on a device resolves that device's copy of the array
  * (hipGetSymbolAddress) and sets a kernel attribute: make it outside a capture.  All calls on one GPU share the array:

@@ -71,12 +71,19 @@ extern "C" int slim_hist_abs_bf16(const void* W, int64_t numel, uint32_t* hist, 
 //  [2B, 3B)          total_loss (inf where not evaluated)
 //  [3B, 3B+16)       coarse losses (11 used)
 //  [3B+16, 3B+32)    coarse indices as int32 (11 used), then scalars
+//  then, as int32: the bins with a non-zero count, listed per thread of a candidate's workgroup in the order that thread
+//  visits them -- count256[256], count1024[1024], list256[ceil(B/256)][256], list1024[ceil(B/1024)][1024] (entry k of
+//  thread t at [k][t]).  A candidate's loss is a sum over ALL bins, thread t of NT adding bins t, t + NT, ... in that
+//  order; a bin with count zero adds +0.0 to a double, so leaving it out changes no bit of any partial sum.  The weights
+//  are bf16: at 20 000 bins over [min |w|, max |w|] the upper binades hold one bf16 value per ~100 bins, and some 5 % of the
+//  bins are occupied.
 struct SearchWs {
     float* pdf;
     float* val;
     float* total_loss;
     float* coarse_loss;
     int32_t* coarse_idx;
+    int32_t *count256, *count1024, *list256, *list1024;
 };
 __host__ __device__ static inline SearchWs search_ws(float* base, int B) {
     SearchWs w;
@@ -85,12 +92,17 @@ __host__ __device__ static inline SearchWs search_ws(float* base, int B) {
     w.total_loss = base + 2 * (int64_t)B;
     w.coarse_loss = base + 3 * (int64_t)B;
     w.coarse_idx = (int32_t*)(base + 3 * (int64_t)B + 16);
+    w.count256 = (int32_t*)(base + 3 * (int64_t)B + 32);
+    w.count1024 = w.count256 + 256;
+    w.list256 = w.count1024 + 1024;
+    w.list1024 = w.list256 + (int64_t)((B + 255) / 256) * 256;
     return w;
 }
 
 extern "C" int64_t slim_quant_search_workspace_bytes(int num_bins) {
     if (num_bins <= 0) return 0;
-    return ((int64_t)3 * num_bins + 32) * (int64_t)sizeof(float);
+    const int64_t B = num_bins;
+    return (3 * B + 32 + 256 + 1024 + (B + 255) / 256 * 256 + (B + 1023) / 1024 * 1024) * (int64_t)sizeof(float);
 }
 
 __device__ __forceinline__ float edge_at(int i, int bins, float lo, float hi, float step) {
@@ -166,6 +178,20 @@ __global__ __launch_bounds__(1024) void rebin_kernel(const uint32_t* __restrict_
         ws.coarse_loss[threadIdx.x] = __builtin_inff();
         ws.coarse_idx[threadIdx.x] = 0;
     }
+    // the occupied bins in the order the threads of a candidate's workgroup visit them (cnt[] is complete since the barrier
+    // above and is only read from here on)
+    {
+        int k = 0;
+        for (int i = threadIdx.x; i < bins; i += 1024)
+            if (cnt[i]) ws.list1024[(k++) * 1024 + threadIdx.x] = i;
+        ws.count1024[threadIdx.x] = k;
+    }
+    if (threadIdx.x < 256) {
+        int k = 0;
+        for (int i = threadIdx.x; i < bins; i += 256)
+            if (cnt[i]) ws.list256[(k++) * 256 + threadIdx.x] = i;
+        ws.count256[threadIdx.x] = k;
+    }
 }
 
 // fmodf(a, b) for finite a >= 0, b > 0 whose quotient is below 2^23, without the library routine's loop: with n =
@@ -230,15 +256,37 @@ __device__ float candidate_loss(const SearchWs& ws, int bins, int index, int q, 
     const float step = alpha / (float)(1 << q);
     const float rstep = 1.0f / step;
     double sq = 0.0, sc = 0.0;
-    for (int j = threadIdx.x; j < bins; j += NT) {
-        const float v = ws.val[j], p = ws.pdf[j];
-        if (j < index) {
-            const float qv = (step == 0.f ? (v / step) : floor_quot_f32(v, step, rstep)) * step;
-            const float d = v - qv;
-            sq += (double)(p * (d * d));
-        } else {
-            const float d = v - alpha;
-            sc += (double)(p * (d * d));
+    static_assert(NT == 256 || NT == 1024, "the occupied bins are listed for workgroups of 256 and 1024 threads");
+    // The regular case -- a positive finite step and no negative bin centre (min |w| >= 0 unless a constant |w| had its range
+    // widened) -- visits the occupied bins only: every term of an empty bin is then +0.0 (finite d, p = 0).  Otherwise
+    // (a candidate at or below zero in the widened range: 0 / 0 and inf * 0 appear, and 0 * NaN is not 0) every bin is
+    // visited and the floor division takes its literal form.
+    if (step > 0.f && step < __builtin_inff() && ws.val[0] >= 0.f) {
+        const int32_t* list = NT == 256 ? ws.list256 : ws.list1024;
+        const int occupied = (NT == 256 ? ws.count256 : ws.count1024)[threadIdx.x];
+        for (int k = 0; k < occupied; ++k) {
+            const int j = list[k * NT + threadIdx.x];
+            const float v = ws.val[j], p = ws.pdf[j];
+            if (j < index) {
+                const float qv = floor_quot_f32(v, step, rstep) * step;
+                const float d = v - qv;
+                sq += (double)(p * (d * d));
+            } else {
+                const float d = v - alpha;
+                sc += (double)(p * (d * d));
+            }
+        }
+    } else {
+        for (int j = threadIdx.x; j < bins; j += NT) {
+            const float v = ws.val[j], p = ws.pdf[j];
+            if (j < index) {
+                const float qv = (step == 0.f ? (v / step) : floor_div_f32(v, step)) * step;
+                const float d = v - qv;
+                sq += (double)(p * (d * d));
+            } else {
+                const float d = v - alpha;
+                sc += (double)(p * (d * d));
+            }
         }
     }
     sq = wave_sum_d(sq);
@@ -275,9 +323,10 @@ __global__ __launch_bounds__(1024) void search_coarse_kernel(float* ws_base, int
 }
 
 // fine scan of [indices[max(tp-1,0)], indices[min(tp+1,10)]), block b evaluates start + b (thousands of workgroups:
-// bound by arithmetic, 256 threads each -- a floor, a fused multiply-add, two comparisons and the squared difference per
-// (candidate, bin) pair; 27 lane-cycles while the floor division still performed its two correctly rounded divisions.  Four candidates per workgroup sharing the fetches of the bins, and the fetches batched eight deep, both
-// measured slower: 77 against 64 us)
+// 256 threads each over the occupied bins -- a floor, a fused multiply-add, two comparisons and the squared difference per
+// (candidate, bin) pair.  While every bin was visited the launch was bound by arithmetic: 64 us at 27 lane-cycles per pair
+// with the floor division's two correctly rounded divisions, 44 us without them; four candidates per workgroup sharing the
+// fetches of the bins, and the fetches batched eight deep, both measured slower then)
 __global__ __launch_bounds__(256) void search_fine_kernel(float* ws_base, int bins, int q) {
     __shared__ double red[8];
     SearchWs ws = search_ws(ws_base, bins);
@@ -412,11 +461,11 @@ extern "C" int slim_quant_search(const uint32_t* hist, int num_bins, int num_bit
 }
 
 // ---- the search without a caller workspace and without any allocation ------------------------------------
-// Search workspace for the largest histogram the search supports (3 * 20000 + 32 floats = 240 128 bytes), as a
+// Search workspace for the largest histogram the search supports (102 016 words = 408 064 bytes for 20 000 bins), as a
 // device array of this library's code object: every GPU the library runs on holds its own copy, at its own address,
 // until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress; the device
 // address it returns (per device) is what the kernels get.
-#define STATIC_SEARCH_FLOATS (3 * MAX_SEARCH_BINS + 32)
+#define STATIC_SEARCH_FLOATS (3 * MAX_SEARCH_BINS + 32 + 256 + 1024 + (MAX_SEARCH_BINS + 255) / 256 * 256 + (MAX_SEARCH_BINS + 1023) / 1024 * 1024)
 #define SLIM_MAX_DEVICES 64
 static __device__ __align__(256) float scratch[STATIC_SEARCH_FLOATS];
 static float* g_scratch_ptr[SLIM_MAX_DEVICES];  // NULL = not resolved on that device yet
@@ -444,8 +493,9 @@ extern "C" int slim_quant_search_noalloc(const uint32_t* hist, int num_bins, int
         }
         ws = g_scratch_ptr[dev];
     }
-    // rebin_kernel rewrites every word the later kernels read (pdf, val, total_loss below num_bins and the 32 coarse
-    // slots), so what an earlier, larger search left above num_bins is never looked at
+    // rebin_kernel rewrites every word the later kernels read (pdf, val, total_loss below num_bins, the 32 coarse slots, the
+    // counts of occupied bins and the list entries below those counts), so what an earlier, larger search left is never
+    // looked at
     return launch_search(hist, num_bins, num_bits, alpha_out, idx_out, sf_out, ws, (hipStream_t)stream);
 }
 

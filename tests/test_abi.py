@@ -38,7 +38,7 @@ def test_errors_are_status_codes_not_exceptions():
     # null pointers are rejected before any GPU work is attempted
     rc = lib.slim_mask_nm(None, None, 4, 8, 2, 4, None, None)
     assert rc == _lib.ERR_INVALID and b"slim_mask_nm" in lib.slim_last_error()
-    assert lib.slim_quant_search_workspace_bytes(512) == (3 * 512 + 32) * 4
+    assert lib.slim_quant_search_workspace_bytes(512) == (3 * 512 + 32 + 256 + 1024 + 512 + 1024) * 4      # + the lists of occupied bins
     assert lib.slim_lowrank_fit_workspace_bytes(1024, 512, 192) > 4 * (1024 + 512) * 192 * 2
     with pytest.raises(ValueError):
         _lib.call("slim_shift_zeros", None, None, 0, None)
