@@ -112,9 +112,9 @@ def cpu_baseline():
 
 # kernel symbol (as a profiler prints it) of each family the in-library timer reports
 FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0,", "gemm_nt_small": "gemm_nt_kernel<1,", "gemm_nt_apply": "gemm_nt_kernel<2,",
-                 "gemm_nt_sketch": "gemm_nt_kernel<3,", "gemm_nt_big": "gemm_nt_kernel<4,", "gemm_nt_residual": "gemm_nt_kernel<5,",
+                 "gemm_nt_sketch": "gemm_nt_dma_kernel<3,", "gemm_nt_big": "gemm_nt_kernel<4,", "gemm_nt_residual": "gemm_nt_kernel<5,",
                  "eigh_tridiag": "tridiag_step_kernel", "eigh_multisect": "tri_multisect_kernel", "eigh_twisted": "tri_twisted_kernel",
-                 "gemm_f32": "f32_gemm_kernel", "pack24": "pack24_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_kernel", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
+                 "gemm_f32": "f32_gemm_kernel", "pack24": "pack24_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
                  "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel",
                  "rs_cheb": "rs_cheb_kernel", "rs_qr": "rs_qr_kernel", "rs_apply": "rs_apply_kernel", "rs_bounds": "rs_bounds_kernel",
                  "rs_infnorm": "rs_infnorm_kernel", "rs_evals": "rs_evals_kernel"}

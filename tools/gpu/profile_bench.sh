@@ -16,7 +16,9 @@ find gpurun_out/prof -name "*.csv" | head -20
 F=$(find gpurun_out/prof/fetch -name "*counter_collection.csv" | head -1)
 W=$(find gpurun_out/prof/write -name "*counter_collection.csv" | head -1)
 # the statistics kernel reads 128 * 2048 * 2 bytes per input channel: 3 launches over 4096 channels and one over 11008 per step
-python tools/pmc_summarize.py "$F" "$W" gpurun_out/prof/r3_pmc_traffic.json "3053453312/launch" "${COMMIT:-unrecorded}" | tail -40
+rm -f gpurun_out/prof/r3_pmc_traffic.json
+python tools/pmc_summarize.py "$F" "$W" gpurun_out/prof/r3_pmc_traffic.json "3053453312/launch" "${COMMIT:-unrecorded}" > gpurun_out/prof/pmc_summary.txt 2>&1 || { tail -5 gpurun_out/prof/pmc_summary.txt; exit 1; }
+tail -40 gpurun_out/prof/pmc_summary.txt
 S=$(find gpurun_out/prof/trace -name "*kernel_stats.csv" | head -1)
 cp "$S" gpurun_out/prof/r3_bench_kernel_stats_single_stream.csv
 head -25 "$S" | cut -c1-200

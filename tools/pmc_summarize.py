@@ -3,7 +3,7 @@ with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE):
 
     python tools/pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <calib bytes> [commit]
 
-The counters' unit is calibrated, not assumed: the statistics kernel (colsumsq_kernel) streams exactly 2 bytes per
+The counters' unit is calibrated, not assumed: the statistics kernel (colsumsq_kernel / colsumsq_tall_kernel) streams exactly 2 bytes per
 activation element with 16-byte loads, so <calib bytes> = the bytes it read over the whole run (bench.py, one step:
 128 * 2048 * 2 * sum of the 7 linears' input widths = 18 656 788 480) fixes the bytes per FETCH_SIZE unit for wide
 streaming reads (on gfx950 these are tallied at half their size, which the calibration absorbs).  WRITE_SIZE is
@@ -29,16 +29,21 @@ def load(path, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    cal_name = next(k for k in fetch if "colsumsq_kernel" in k)
+    # (the statistics kernel has two forms, colsumsq_kernel and colsumsq_tall_kernel<n>: same bytes, both count)
+    cal = [k for k in fetch if "colsumsq_" in k]
+    if not cal:
+        raise SystemExit("no launch of the statistics kernel (colsumsq_*) in " + sys.argv[1])
+    cal_name = " + ".join(cal)
+    cal_launches, cal_counter = sum(fetch[k][0] for k in cal), sum(fetch[k][1] for k in cal)
     # "<bytes>/launch": the average bytes per launch of the calibration kernel instead of the run's total
-    known = float(sys.argv[4][:-7]) * fetch[cal_name][0] if sys.argv[4].endswith("/launch") else float(sys.argv[4])
-    read_unit = known / fetch[cal_name][1]
+    known = float(sys.argv[4][:-7]) * cal_launches if sys.argv[4].endswith("/launch") else float(sys.argv[4])
+    read_unit = known / cal_counter
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from slim_amd.build import source_fingerprint
     # the library sources the counters were collected on (run this right after the counter passes, on the same tree) and,
     # when given, the commit that holds them: bench.py quotes these figures only while the fingerprint still matches
     out = {"source_fingerprint": source_fingerprint(), "commit": sys.argv[5] if len(sys.argv) > 5 else None,
-           "calibration": {"kernel": cal_name, "known_bytes_total": known, "counter_total": fetch[cal_name][1],
+           "calibration": {"kernel": cal_name, "known_bytes_total": known, "counter_total": cal_counter,
                            "bytes_per_fetch_unit": read_unit, "bytes_per_write_unit": 1024.0}, "kernels": {}}
     for name in sorted(set(fetch) | set(write)):
         n = fetch.get(name, write.get(name))[0]
