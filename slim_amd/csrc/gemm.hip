@@ -90,7 +90,18 @@ __device__ __forceinline__ void gemm_tile_origin(GemmArgs& g, const GemmArgs& gi
     // served by L2
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     int tm, tn;
-    if (g.sym && g.sym_block > 1) {
+    if (g.sym && BM == 2 * BN) {
+        // symmetric product on tiles twice as tall as wide: row tm (256 rows) holds the tiles from column 2 tm on, i.e.
+        // every tile with an element on or above the diagonal; the two leftmost of a row straddle the diagonal and compute
+        // a few elements below it as well (the same values their mirror images receive: the products of a sum commute)
+        tm = 0;
+        int rest = wgid;
+        while (rest >= tiles_n - 2 * tm) {
+            rest -= tiles_n - 2 * tm;
+            ++tm;
+        }
+        tn = 2 * tm + rest;
+    } else if (g.sym && g.sym_block > 1) {
         // tiles on and above the diagonal in square blocks of sym_block x sym_block tiles (block rows, then the tiles of a
         // block): the run of consecutive tiles that one XCD works on at a time then shares sym_block row panels and
         // sym_block column panels in its L2, where a row-by-row order shares one row panel and as many column panels as
@@ -931,6 +942,11 @@ static const bool g_dma_tiles = [] {
     const char* v = getenv("SLIM_GEMM_DMA");
     return !(v && v[0] == '0');
 }();
+// SLIM_GEMM_SYM_RECT=0: the big symmetric products stay on the square register-staged tile (A/B aid)
+static const bool g_sym_rect = [] {
+    const char* v = getenv("SLIM_GEMM_SYM_RECT");
+    return !(v && v[0] == '0');
+}();
 static int gemm_pick_tile(int family) {
     if (g_tile_override >= 0) return g_tile_override;
     return g_family_tile[family] >= 0 ? g_family_tile[family] : TILE_128x128;
@@ -978,23 +994,36 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
                          g.splits <= 1 && !g.C32 && !g.Wn && !g.poly_G && !g.sym && g.beta == 0.f;
     // ... fed by LDS-DMA when the reduction is whole 64-deep steps (SLIM_GEMM_DMA=0: register staging everywhere, an A/B aid)
     if (tall_ok && (288 - g.M % 288) % 288 <= (128 - g.M % 128) % 128) tile = g_dma_tiles && g.Kd % 64 == 0 ? TILE_DMA_288x128 : TILE_288x128;
+    // the big symmetric products with mirrored bf16 output (C = E^T E of the fit) on the 256 x 128 tile fed by LDS-DMA
+    if (g_tile_override < 0 && g_family_tile[fam] < 0 && g_dma_tiles && g_sym_rect && fam == FAM_BIG && g.sym && g.M == g.N && g.A == g.B &&
+        g.lda == g.ldb && g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f &&
+        g.Kd % 64 == 0 && g.M >= 1024 &&
+        (g.nptr < 1 || g.Kdp0 % 64 == 0) && (g.nptr < 2 || g.Kdp1 % 64 == 0) && (g.nptr < 3 || g.Kdp2 % 64 == 0) && (g.nptr < 4 || g.Kdp3 % 64 == 0))
+        tile = TILE_DMA_256x128;
     // (a forced DMA tile falls back where its conditions do not hold: whole 64-deep K-steps; plain bf16 outputs for 288 x 128)
     if (kTileStages[tile] > 0 && g.Kd % 64 != 0) tile = TILE_128x128;
     if (tile == TILE_DMA_288x128 && (g.splits > 1 || g.C32 || g.Wn || g.poly_G || g.sym || g.beta != 0.f)) tile = TILE_DMA_128x128;
     const int BM = kTileM[tile], BN = kTileN[tile], NT = kTileThreads[tile];
     // symmetric products: with split-K the reduction mirrors the lower tiles; without it the workgroups of the upper
     // tiles write their tile and its transpose, which the caller asks for by aiming C^T at C itself (bf16 outputs only)
-    const bool sym_shape = g.M == g.N && BM == BN && g.A == g.B && g.lda == g.ldb;
+    const bool sym_shape = g.M == g.N && (BM == BN || tile == TILE_DMA_256x128) && g.A == g.B && g.lda == g.ldb;
     const int tiles_m_early = (g.M + BM - 1) / BM;
     const bool sym_split = g.splits > 1 && !g.Ct16;
     const bool sym_mirror = g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f;
+    // (the rectangular tile serves the bf16 mirrored form only)
+    if (g.sym && tile == TILE_DMA_256x128 && !(sym_shape && sym_mirror)) g.sym = 0;
     // ... or, for an fp32 output alone (possibly accumulated into: beta), its fp32 transpose
     const bool sym_mirror32 = g.splits <= 1 && g.C32 && !g.C16 && !g.Ct16 && !g.Wn && !g.poly_G && batch == 1 && NT == 256;
     if (g.sym && !(sym_shape && (sym_split || sym_mirror || sym_mirror32))) g.sym = 0;
     g.mirror32 = g.sym && sym_mirror32 && !sym_split ? 1 : 0;
     g.sym_block = g.sym && tiles_m_early >= 16 ? g_sym_block : 0;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
-    const int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
+    int64_t tiles = g.sym ? tiles_m * (tiles_m + 1) / 2 : tiles_m * ((g.N + BN - 1) / BN);
+    if (g.sym && BM == 2 * BN) {
+        const int64_t tiles_n = (g.N + BN - 1) / BN;
+        tiles = 0;
+        for (int64_t tm = 0; tm < tiles_m; ++tm) tiles += tiles_n - 2 * tm;
+    }
     SLIM_REQUIRE(tiles < ((int64_t)1 << 31), "slim_gemm_nt_bf16: too many tiles");
     const int loop_bytes = kTileStages[tile] > 0 ? kTileStages[tile] * (BM + BN) * 128
                                                  : 2 * (BM + BN) * (kTileBK[tile] + LDS_PAD) * (int)sizeof(bf16_t);
@@ -1119,6 +1148,9 @@ extern "C" int slim_gemm_nt_bf16(const void* A, int64_t lda, const void* Bt, int
     g.ldc16 = ldc16;
     g.Ct16 = (bf16_t*)Ct_bf16;
     g.ldct = ldct;
+    // X X^T with the same buffer given for C and C^T (bf16 only): the tiles on and above the diagonal are computed and
+    // mirrored, as the fit does for its Gram matrices
+    g.sym = A == Bt && lda == ldb && M == N && C_bf16 && Ct_bf16 == C_bf16 && ldct == ldc16 && !C_f32 ? 1 : 0;
     return slim_gemm_launch(g, stream);
 }
 

@@ -309,9 +309,10 @@ def transpose(x, out=None):
     return out
 
 
-def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False, C16=None):
+def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False, out_t=False, C16=None, mirrored=False):
     """C = alpha * A @ Bt.T (+ beta * C32). Returns (C fp32 | None, C bf16 | None, C^T bf16 | None).  C16 (optional): a
-    contiguous bf16 [M, N] tensor that receives the bf16 result (implies out_bf16)."""
+    contiguous bf16 [M, N] tensor that receives the bf16 result (implies out_bf16).  mirrored=True (Bt is A, bf16 output
+    only): A A^T with the tiles on and above the diagonal computed and mirrored into the rest (C^T returned is C itself)."""
     A = _chk(A, BF16, "A")
     Bt = _chk(Bt, BF16, "Bt")
     M, Kd = A.shape
@@ -327,6 +328,11 @@ def gemm_nt(A, Bt, alpha=1.0, beta=0.0, C32=None, out_f32=False, out_bf16=False,
     elif out_bf16:
         C16 = torch.empty(M, N, dtype=BF16, device=dev)
     Ct = torch.empty(N, M, dtype=BF16, device=dev) if out_t else None
+    if mirrored:
+        if Bt.data_ptr() != A.data_ptr() or C32 is not None or M != N:
+            raise ValueError("mirrored: A A^T with a bf16 output only")
+        C16 = C16 if C16 is not None else torch.empty(M, N, dtype=BF16, device=dev)
+        Ct = C16
     _lib.call("slim_gemm_nt_bf16", _p(A), Kd, _p(Bt), Kd, M, N, Kd, float(alpha), float(beta), _p(C32), N, _p(C16), N,
               _p(Ct), M, _stream())
     return C32, C16, Ct

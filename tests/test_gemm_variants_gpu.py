@@ -113,3 +113,22 @@ def test_dma_tiles_equal_square_tile(variant):
             assert torch.equal(a, b), (variant, M, N, Kd, k)
         ref = 0.5 * (A.double() @ Bt.double().t())
         assert (outs[1][0].double() - ref).abs().max().item() <= 1e-5 * Kd ** 0.5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,kd", [(4096, 4096), (1024, 192), (1280, 640), (1100, 256), (2048, 11008)])
+def test_mirrored_product_rectangular_tiles_equal_square_tiles(n, kd):
+    """X X^T with mirrored bf16 output (the fit's Gram matrices C = E^T E): the 256 x 128 tiles fed by LDS-DMA -- rows of
+    tiles from the diagonal on, the two leftmost of a row straddling it -- against the square register-staged tiles and
+    against the full product: identical, and symmetric."""
+    from slim_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(n + kd)
+    X = torch.randn(n, kd, generator=g, device="cuda").to(torch.bfloat16)
+    outs = {}
+    for v in (0, 7, -1):
+        _lib.query("slim_gemm_set_tile", v)
+        outs[v] = ops.gemm_nt(X, X, mirrored=True)[1]
+    _lib.query("slim_gemm_set_tile", 0)
+    full = ops.gemm_nt(X, X.clone(), out_bf16=True)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], full) and torch.equal(outs[7], full) and torch.equal(outs[-1], full)
+    assert torch.equal(full, full.t())
