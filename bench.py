@@ -110,9 +110,10 @@ def cpu_baseline():
             "seconds": dt, "block_of_7_linears_extrapolated_s": block_s}
 
 
-# kernel symbol (as a profiler prints it) of each family the in-library timer reports
-FAMILY_KERNEL = {"gemm_nt_gram": "gemm_nt_kernel<0,", "gemm_nt_small": "gemm_nt_kernel<1,", "gemm_nt_apply": "gemm_nt_kernel<2,",
-                 "gemm_nt_sketch": "gemm_nt_dma_kernel<3,", "gemm_nt_big": "gemm_nt_kernel<4,", "gemm_nt_residual": "gemm_nt_kernel<5,",
+# kernel symbol (as a profiler prints it; a distinguishing part of it: the GEMM families run on the register-staged
+# gemm_nt_kernel<family, ...> or on gemm_nt_dma_kernel<family, ...>) of each family the in-library timer reports
+FAMILY_KERNEL = {"gemm_nt_gram": "_kernel<0,", "gemm_nt_small": "_kernel<1,", "gemm_nt_apply": "_kernel<2,",
+                 "gemm_nt_sketch": "_kernel<3,", "gemm_nt_big": "_kernel<4,", "gemm_nt_residual": "_kernel<5,",
                  "eigh_tridiag": "tridiag_step_kernel", "eigh_multisect": "tri_multisect_kernel", "eigh_twisted": "tri_twisted_kernel",
                  "gemm_f32": "f32_gemm_kernel", "pack24": "pack24_kernel", "splitk_reduce": "splitk_reduce_kernel", "colsumsq": "colsumsq_", "mask_nm": "mask_nm4_kernel<true>", "error_matrix": "error_matrix_kernel",
                  "hist_bf16": "hist_bf16_kernel", "fake_quant_pt": "fake_quant_pt_kernel", "transpose": "transpose_bf16_kernel",
