@@ -441,7 +441,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
         }
     }
     gemm_stamp(g, 5);
-    if (ALL_FORMS && g.mirror32 && !split && row0 != col0) {
+    // (tiles twice as tall as wide: only the tiles right of the diagonal's 2 x 2 group are mirrored -- the positions the two
+    // straddling tiles of a row would mirror into are computed directly, by themselves or by their neighbour)
+    const bool mirrors = BM == 2 * BN ? col0 >= row0 + BM : row0 != col0;
+    if (ALL_FORMS && g.mirror32 && !split && mirrors) {
         // symmetric fp32 product: this tile's transpose goes to the tile below the diagonal, which no workgroup computes.
         // Lanes walk along the tile's rows (the output's columns): 256 contiguous bytes per wave and output row, and the odd
         // LDS row stride keeps the column-wise reads conflict-free.
@@ -451,7 +454,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
             if (row0 + r < g.M && col0 + c < g.N) g.C32[(int64_t)(col0 + c) * g.ldc32 + row0 + r] = T[r * TS + c];
         }
     }
-    if (g.Ct16 && !split) {
+    if (g.Ct16 && !split && !(g.sym && BM == 2 * BN && !mirrors)) {
         // a wave writes eight rows of C^T (tile columns) at a time, 8 lanes x 16 bytes = 128 contiguous bytes each
         const int lane = t & 63, wave = t >> 6;
         const bool vt = (g.ldct & 7) == 0 && ((uintptr_t)g.Ct16 & 15) == 0;
@@ -995,11 +998,14 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     // ... fed by LDS-DMA when the reduction is whole 64-deep steps (SLIM_GEMM_DMA=0: register staging everywhere, an A/B aid)
     if (tall_ok && (288 - g.M % 288) % 288 <= (128 - g.M % 128) % 128) tile = g_dma_tiles && g.Kd % 64 == 0 ? TILE_DMA_288x128 : TILE_288x128;
     // the big symmetric products with mirrored bf16 output (C = E^T E of the fit) on the 256 x 128 tile fed by LDS-DMA
-    if (g_tile_override < 0 && g_family_tile[fam] < 0 && g_dma_tiles && g_sym_rect && fam == FAM_BIG && g.sym && g.M == g.N && g.A == g.B &&
-        g.lda == g.ldb && g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f &&
-        g.Kd % 64 == 0 && g.M >= 1024 &&
-        (g.nptr < 1 || g.Kdp0 % 64 == 0) && (g.nptr < 2 || g.Kdp1 % 64 == 0) && (g.nptr < 3 || g.Kdp2 % 64 == 0) && (g.nptr < 4 || g.Kdp3 % 64 == 0))
-        tile = TILE_DMA_256x128;
+    {
+        const bool form16 = g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && g.beta == 0.f;
+        const bool form32 = g.C32 && !g.C16 && !g.Ct16 && batch == 1;          // (the calibration Gram matrix, accumulated into)
+        if (g_tile_override < 0 && g_family_tile[fam] < 0 && g_dma_tiles && g_sym_rect && fam == FAM_BIG && g.sym && g.M == g.N && g.A == g.B &&
+            g.lda == g.ldb && g.splits <= 1 && (form16 || form32) && !g.Wn && !g.poly_G && g.Kd % 64 == 0 && g.M >= 1024 &&
+            (g.nptr < 1 || g.Kdp0 % 64 == 0) && (g.nptr < 2 || g.Kdp1 % 64 == 0) && (g.nptr < 3 || g.Kdp2 % 64 == 0) && (g.nptr < 4 || g.Kdp3 % 64 == 0))
+            tile = TILE_DMA_256x128;
+    }
     // (a forced DMA tile falls back where its conditions do not hold: whole 64-deep K-steps; plain bf16 outputs for 288 x 128)
     if (kTileStages[tile] > 0 && g.Kd % 64 != 0) tile = TILE_128x128;
     if (tile == TILE_DMA_288x128 && (g.splits > 1 || g.C32 || g.Wn || g.poly_G || g.sym || g.beta != 0.f)) tile = TILE_DMA_128x128;
@@ -1010,11 +1016,11 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
     const int tiles_m_early = (g.M + BM - 1) / BM;
     const bool sym_split = g.splits > 1 && !g.Ct16;
     const bool sym_mirror = g.splits <= 1 && g.C16 && g.Ct16 == g.C16 && g.ldct == g.ldc16 && !g.C32 && !g.Wn && !g.poly_G && g.beta == 0.f;
-    // (the rectangular tile serves the bf16 mirrored form only)
-    if (g.sym && tile == TILE_DMA_256x128 && !(sym_shape && sym_mirror)) g.sym = 0;
     // ... or, for an fp32 output alone (possibly accumulated into: beta), its fp32 transpose
-    const bool sym_mirror32 = g.splits <= 1 && g.C32 && !g.C16 && !g.Ct16 && !g.Wn && !g.poly_G && batch == 1 && NT == 256;
+    const bool sym_mirror32 = g.splits <= 1 && g.C32 && !g.C16 && !g.Ct16 && !g.Wn && !g.poly_G && batch == 1 && (NT == 256 || tile == TILE_DMA_256x128);
     if (g.sym && !(sym_shape && (sym_split || sym_mirror || sym_mirror32))) g.sym = 0;
+    // (the rectangular tile serves the mirrored forms only, bf16 or fp32, not the split-K one)
+    if (g.sym && tile == TILE_DMA_256x128 && !(sym_shape && (sym_mirror || sym_mirror32))) g.sym = 0;
     g.mirror32 = g.sym && sym_mirror32 && !sym_split ? 1 : 0;
     g.sym_block = g.sym && tiles_m_early >= 16 ? g_sym_block : 0;
     const int64_t tiles_m = (g.M + BM - 1) / BM;

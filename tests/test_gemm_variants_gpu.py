@@ -132,3 +132,25 @@ def test_mirrored_product_rectangular_tiles_equal_square_tiles(n, kd):
     torch.cuda.synchronize()
     assert torch.equal(outs[0], full) and torch.equal(outs[7], full) and torch.equal(outs[-1], full)
     assert torch.equal(full, full.t())
+
+
+@pytest.mark.parametrize("K,T", [(1280, 4096), (2048, 8192), (1096, 2048)])
+def test_gram_accumulation_rectangular_tiles_equal_square_tiles(K, T):
+    """slim_gram_accum (H = (2/n) sum X^T X, fp32, accumulated into: slim/sparsegpt.py:28-39) on the 256 x 128 tiles fed by
+    LDS-DMA against the square register-staged tiles, two calls in a row: identical H, symmetric -- the tiles that straddle
+    the diagonal compute their part below it themselves and nothing is mirrored into a position that is also computed."""
+    from slim_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(K + T)
+    X = [(torch.randn(T, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16) for _ in range(2)]
+    H = {}
+    for v in (0, -1, 7):
+        _lib.query("slim_gemm_set_tile", v)
+        h = torch.zeros(K, K, device="cuda")
+        for j in range(2):
+            ops.gram_accum(X[j], h, j, 1)
+        H[v] = h
+    torch.cuda.synchronize()
+    assert torch.equal(H[0], H[-1]) and torch.equal(H[0], H[7])
+    assert torch.equal(H[0], H[0].t())
+    ref = sum(x.double().t() @ x.double() for x in X) * (2.0 / 2)
+    assert (H[0].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
