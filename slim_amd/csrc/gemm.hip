@@ -641,8 +641,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // every wave is past the previous K-step's fragment reads: its buffer takes stage kt + STAGES - 1
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, buf == 0 ? STAGES - 1 : buf - 1);
         const char* a_base = lds + buf * STAGE_BYTES + a_off;
         const char* b_base = lds + buf * STAGE_BYTES + b_off;
         // the first 32-deep half's fragments are requested together, the second half's while the first half's products run
@@ -656,6 +654,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
             for (int i = 0; i < FM; ++i) af[ks][i] = *(const bf16x8*)(a_base + i * 16 * 128 + x);
         };
         fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave is past the previous K-step's fragment reads: its buffer takes stage kt + STAGES - 1.  Requested behind
+        // this step's first fragment reads, not ahead of them: the reads are what the matrix instructions wait for (5 % of the
+        // loop; a raised wave priority around the matrix instructions measured nothing)
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, buf == 0 ? STAGES - 1 : buf - 1);
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
 #pragma unroll
