@@ -602,3 +602,21 @@ def test_exact_remainder_equals_fmodf(ops):
         fast, ref = ops.floordiv_probe(g2d(a.contiguous()), g2d(b.contiguous()))
         assert torch.equal(fast.view(torch.int32), ref.view(torch.int32))
         assert torch.equal(ref.cpu(), torch.floor_divide(a, b))
+
+
+def test_tall_statistics_kernel_equals_slab_kernel(ops):
+    """Samples of 2048 tokens take the statistics kernel that walks eight slabs of 256 rows per workgroup and stores the
+    per-slab sums at the end; the same rows presented as chunks of 256 take the one-slab kernel.  A sample's sum must be the
+    eight slab sums added in order (what the fold does), bit for bit -- with a ragged last column block."""
+    g = torch.Generator(device=DEV).manual_seed(31)
+    n, rows, K = 128, 2048, 2056
+    x = (torch.randn(n * rows, K, generator=g, device=DEV) * torch.exp(torch.randn(K, generator=g, device=DEV))).to(torch.bfloat16)
+    tall = ops.colsumsq(x, n)                                   # [128, K]: eight slabs per workgroup
+    slabs = ops.colsumsq(x, n * 8).reshape(n, 8, K)             # [128, 8, K]: one slab per workgroup
+    want = torch.zeros(n, K, device=DEV)
+    for s in range(8):
+        want = want + slabs[:, s]
+    torch.cuda.synchronize()
+    assert torch.equal(tall, want)
+    ref = x[:rows].double().pow(2).sum(0)
+    assert (tall[0].double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
