@@ -27,12 +27,12 @@
 // TILE_288x128 (512 threads, 2 x 4 waves of 144 x 32): for products whose M is the subspace dimension of the fit (576 = 2 x 288,
 // 1152 = 4 x 288): no padded rows, and the four (l x Dm) products of a chain are 256 tiles -- one per CU, two waves per SIMD --
 // instead of 640 tiles of 128 x 128 on 512 workgroup slots
-enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, TILE_288x128, TILE_DMA_288x128, TILE_DMA_128x128, TILE_DMA_256x128, TILE_COUNT };
-static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 288, 288, 128, 256};
-static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 128, 128, 128};
-static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64};
-static const int kTileThreads[TILE_COUNT] = {256, 256, 256, 256, 512, 512, 256, 512};
-static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 0, 3, 4, 3};       // LDS-DMA stages (0: register staging, two buffers)
+enum { TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, TILE_288x128, TILE_DMA_288x128, TILE_DMA_128x128, TILE_DMA_256x128, TILE_DMA_128x128_S2, TILE_COUNT };
+static const int kTileM[TILE_COUNT] = {128, 128, 64, 64, 288, 288, 128, 256, 128};
+static const int kTileN[TILE_COUNT] = {128, 64, 128, 64, 128, 128, 128, 128, 128};
+static const int kTileBK[TILE_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 64};
+static const int kTileThreads[TILE_COUNT] = {256, 256, 256, 256, 512, 512, 256, 512, 256};
+static const int kTileStages[TILE_COUNT] = {0, 0, 0, 0, 0, 3, 4, 3, 2};       // LDS-DMA stages (0: register staging, two buffers)
 
 // BKT elements of the reduction per tile row: BKT / 8 threads cover a row, NT / (BKT / 8) rows per pass of the NT threads; the
 // last pass may cover fewer rows than that (288-row tiles with 512 threads)
@@ -892,6 +892,7 @@ static gemm_kernel_t gemm_kernel_of(int tile) {
         case TILE_DMA_288x128: return gemm_nt_dma_kernel<FAMILY, 9, 2, 2, 4, 3, false>;
         case TILE_DMA_128x128: return gemm_nt_dma_kernel<FAMILY, 4, 4, 2, 2, 4, true>;
         case TILE_DMA_256x128: return gemm_nt_dma_kernel<FAMILY, 4, 4, 4, 2, 3, true>;
+        case TILE_DMA_128x128_S2: return gemm_nt_dma_kernel<FAMILY, 4, 4, 2, 2, 2, true>;
         default: return gemm_nt_kernel<FAMILY, 4, 4>;
     }
 }
@@ -1009,6 +1010,13 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
             (g.nptr < 1 || g.Kdp0 % 64 == 0) && (g.nptr < 2 || g.Kdp1 % 64 == 0) && (g.nptr < 3 || g.Kdp2 % 64 == 0) && (g.nptr < 4 || g.Kdp3 % 64 == 0))
             tile = TILE_DMA_256x128;
     }
+    // the short products of the fit (Gram slices, l x l x l, tall x (l x l), residual: a few K-steps, latency-bound) on the
+    // two-stage 128 x 128 tile fed by LDS-DMA: the same prefetch distance as register staging without its staging
+    // registers and LDS stores, two workgroups per CU as before (Gram slices 23 -> 20 us, l x l x l 18 -> 16, tall 27 -> 25)
+    if (g_tile_override < 0 && g_family_tile[fam] < 0 && g_dma_tiles && tile == TILE_128x128 &&
+        (fam == FAM_GRAM || fam == FAM_SMALL || fam == FAM_APPLY || fam == FAM_RESIDUAL) && g.Kd % 64 == 0 &&
+        (g.nptr < 1 || g.Kdp0 % 64 == 0) && (g.nptr < 2 || g.Kdp1 % 64 == 0) && (g.nptr < 3 || g.Kdp2 % 64 == 0) && (g.nptr < 4 || g.Kdp3 % 64 == 0))
+        tile = TILE_DMA_128x128_S2;
     // (a forced DMA tile falls back where its conditions do not hold: whole 64-deep K-steps; plain bf16 outputs for 288 x 128)
     if (kTileStages[tile] > 0 && g.Kd % 64 != 0) tile = TILE_128x128;
     if (tile == TILE_DMA_288x128 && (g.splits > 1 || g.C32 || g.Wn || g.poly_G || g.sym || g.beta != 0.f)) tile = TILE_DMA_128x128;

@@ -83,7 +83,7 @@ def test_tall_tile_equals_square_tile(M, N, Kd):
     assert (C16.double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8])
 def test_dma_tiles_equal_square_tile(variant):
     """The tiles fed by LDS-DMA several K-steps ahead (288 x 128, 128 x 128, 256 x 128) against the register-staged 128 x 128
     tile: the same fp32 sums in the same order, so identical outputs in every form -- full and ragged shapes, reductions
