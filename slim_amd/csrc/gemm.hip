@@ -1008,7 +1008,9 @@ int slim_gemm_launch(const GemmArgs& g_in, void* stream) {
         if (g_tile_override < 0 && g_family_tile[fam] < 0 && g_dma_tiles && g_sym_rect && fam == FAM_BIG && g.sym && g.M == g.N && g.A == g.B &&
             g.lda == g.ldb && g.splits <= 1 && (form16 || form32) && !g.Wn && !g.poly_G && g.Kd % 64 == 0 && g.M >= 1024 &&
             (g.nptr < 1 || g.Kdp0 % 64 == 0) && (g.nptr < 2 || g.Kdp1 % 64 == 0) && (g.nptr < 3 || g.Kdp2 % 64 == 0) && (g.nptr < 4 || g.Kdp3 % 64 == 0))
-            tile = TILE_DMA_256x128;
+            // (the fp32 form on the two-stage square tile: as fast at K = 11008 and, with 528 instead of 272 tiles, better
+            // balanced at K = 4096 -- 0.61 against 0.68 ms)
+            tile = form32 ? TILE_DMA_128x128_S2 : TILE_DMA_256x128;
     }
     // the short products of the fit (Gram slices, l x l x l, tall x (l x l), residual: a few K-steps, latency-bound) on the
     // two-stage 128 x 128 tile fed by LDS-DMA: the same prefetch distance as register staging without its staging
